@@ -1,0 +1,110 @@
+"""ctypes binding of include/g2048.h (lib2048_hip.so).
+
+There is no CPU implementation: if the shared library has not been built, importing the symbols
+fails loudly; if it is built but no GPU is visible, `g2048_create` returns G2048_ERR_NODEV and
+`check` raises.  Build with `python -c "import __graft_entry__ as g; g.build()"` or
+`make -C 2048_amd/csrc`.
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_uint8, c_uint32, c_uint64, c_void_p
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'lib2048_hip.so')
+
+OK, ERR_ARG, ERR_HIP, ERR_NOMEM, ERR_STATE, ERR_NODEV = 0, -1, -2, -3, -4, -5
+LANE_HAS_PREV, LANE_DONE = 1, 2
+
+
+class G2048Error(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(f'g2048 status {status}: {message}')
+        self.status = status
+
+
+class Stats(ctypes.Structure):
+    _fields_ = [('episodes', c_uint64), ('moves', c_uint64), ('score_sum', c_uint64), ('best_score', c_uint64),
+                ('max_tile', c_uint64 * 20), ('overflow16', c_uint64)]
+
+
+_P = c_void_p          # opaque context / generic buffers (numpy arrays are passed by address)
+
+# name -> (restype, argtypes); every entry point declared in include/g2048.h
+SIGNATURES = {
+    'g2048_abi_version': (c_int, []),
+    'g2048_strerror': (c_char_p, [c_int]),
+    'g2048_device_count': (c_int, [POINTER(c_int)]),
+    'g2048_num_feat': (c_int, [c_int]),
+    'g2048_table_slots': (c_int64, [c_int]),
+    'g2048_feature_layout': (c_int, [c_int, _P, _P]),
+    'g2048_create': (c_int, [c_int, c_uint32, c_int, c_uint64, c_uint64, POINTER(_P)]),
+    'g2048_destroy': (c_int, [_P]),
+    'g2048_last_error': (c_char_p, [_P]),
+    'g2048_sync': (c_int, [_P]),
+    'g2048_timer_start': (c_int, [_P]),
+    'g2048_timer_stop': (c_int, [_P, POINTER(c_float)]),
+    'g2048_set_boards': (c_int, [_P, _P]),
+    'g2048_get_boards': (c_int, [_P, _P]),
+    'g2048_set_scores': (c_int, [_P, _P]),
+    'g2048_get_scores': (c_int, [_P, _P]),
+    'g2048_set_rng': (c_int, [_P, _P]),
+    'g2048_get_rng': (c_int, [_P, _P]),
+    'g2048_get_carry': (c_int, [_P, _P, _P, _P]),
+    'g2048_clear_carry': (c_int, [_P]),
+    'g2048_reset': (c_int, [_P]),
+    'g2048_set_auto_reset': (c_int, [_P, c_int]),
+    'g2048_move_all': (c_int, [_P, _P, _P, _P]),
+    'g2048_apply_moves': (c_int, [_P, _P, _P]),
+    'g2048_terminal': (c_int, [_P, _P, _P, _P]),
+    'g2048_spawn': (c_int, [_P, _P, _P]),
+    'g2048_spawn_injected': (c_int, [_P, _P, _P]),
+    'g2048_step_random': (c_int, [_P, c_uint32]),
+    'g2048_features': (c_int, [_P, _P]),
+    'g2048_weights_set': (c_int, [_P, _P, c_int64]),
+    'g2048_weights_get': (c_int, [_P, _P, c_int64]),
+    'g2048_weights_init': (c_int, [_P, c_uint64, c_float]),
+    'g2048_evaluate': (c_int, [_P, _P]),
+    'g2048_eval_select': (c_int, [_P, _P, _P, _P]),
+    'g2048_update': (c_int, [_P, _P, _P, c_int64]),
+    'g2048_td_steps': (c_int, [_P, c_float, c_uint32]),
+    'g2048_stats_get': (c_int, [_P, POINTER(Stats)]),
+    'g2048_stats_reset': (c_int, [_P]),
+    'g2048_weights_device_ptr': (c_int, [_P, POINTER(_P), POINTER(c_int64)]),
+    'g2048_delta_begin': (c_int, [_P]),
+    'g2048_delta_extract': (c_int, [_P, _P]),
+    'g2048_delta_apply': (c_int, [_P, _P]),
+    'g2048_delta_device_ptr': (c_int, [_P, POINTER(_P)]),
+    'g2048_td_steps_profiled': (c_int, [_P, c_float, c_uint32, POINTER(c_float), POINTER(c_float)]),
+    'g2048_stream_handle': (c_int, [_P, POINTER(_P)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load lib2048_hip.so (once).  Raises if it is missing — there is no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise G2048Error(ERR_NODEV, f'{LIB_PATH} is not built; run __graft_entry__.build() '
+                                        f'(hipcc --offload-arch=gfx950).  There is no CPU fallback.')
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)          # AttributeError here = header and library disagree
+            fn.restype = res
+            fn.argtypes = args
+        if lib.g2048_abi_version() != 1:
+            raise G2048Error(ERR_STATE, 'ABI version mismatch')
+        _lib = lib
+    return _lib
+
+
+def check(status, ctx=None):
+    if status != OK:
+        lib = load()
+        msg = lib.g2048_strerror(status).decode()
+        if ctx:
+            detail = lib.g2048_last_error(ctx).decode()
+            if detail:
+                msg += ': ' + detail
+        raise G2048Error(status, msg)

@@ -1,0 +1,227 @@
+// n-tuple index encoders f_2 .. f_6 (game2048/r_learning.py:17-69) and the D4 images of QAgent.update
+// (r_learning.py:207-214) on a nibble-packed board.  Pure integer C++ (device code; host compile only for
+// tests/hostcheck).
+//
+// Packed form: R[r] = x[r,0]<<12 | x[r,1]<<8 | x[r,2]<<4 | x[r,3]   (row r, leftmost cell most significant)
+//              C[c] = x[0,c]<<12 | x[1,c]<<8 | x[2,c]<<4 | x[3,c]   (column c, top cell most significant)
+// which are exactly the reference's "x_hor" / "x_vert" 4-tuple indices (r_learning.py:41-42), so every other
+// feature is a bit-field of them.  In this form the dihedral group is nearly free: transpose swaps R and C,
+// a left-right mirror reverses the nibbles of every R and the order of C, an up-down mirror the converse.
+//
+// Flat weight table: feature-major, groups in weight_signature order (r_learning.py:136-149):
+//   n = 2,3,4: num_feat x 16^n;  n = 5: 17 x 16^4 then 4 x 16^5;  n = 6: ... then 12 x 14^6.
+#pragma once
+#include "board_ops.hpp"
+
+namespace g2048 {
+
+struct Packed {
+    uint32_t R[4];
+    uint32_t C[4];
+};
+
+template <int N> struct Shape;
+template <> struct Shape<2> { static constexpr int F = 24; static constexpr uint32_t SLOTS = 24u * 256u; };
+template <> struct Shape<3> { static constexpr int F = 52; static constexpr uint32_t SLOTS = 52u * 4096u; };
+template <> struct Shape<4> { static constexpr int F = 17; static constexpr uint32_t SLOTS = 17u * 65536u; };
+template <> struct Shape<5> { static constexpr int F = 21; static constexpr uint32_t SLOTS = 17u * 65536u + 4u * 1048576u; };
+template <> struct Shape<6> { static constexpr int F = 33; static constexpr uint32_t SLOTS = 17u * 65536u + 4u * 1048576u + 12u * 7529536u; };
+
+constexpr uint32_t QUAD_BASE = 0u;                              // 17 four-cell features
+constexpr uint32_t CROSS_BASE = 17u * 65536u;                   // 4 five-cell features
+constexpr uint32_t HEX_BASE = CROSS_BASE + 4u * 1048576u;       // 12 six-cell base-14 features
+constexpr uint32_t HEX_SIZE = 7529536u;                         // 14^6
+
+G2048_HD uint32_t pack16(uint32_t w) {      // bytes b0..b3 (cells 0..3 of a line) -> b0<<12|b1<<8|b2<<4|b3
+    return ((w & 0xFu) << 12) | ((w >> 8 & 0xFu) << 8) | ((w >> 16 & 0xFu) << 4) | (w >> 24 & 0xFu);
+}
+
+G2048_HD uint32_t nibrev16(uint32_t x) {
+    return ((x & 0xFu) << 12) | ((x & 0xF0u) << 4) | ((x >> 4) & 0xF0u) | ((x >> 12) & 0xFu);
+}
+
+// rows: row words of the board, cols: column words (transpose)
+G2048_HD Packed pack_board(const uint32_t rows[4], const uint32_t cols[4]) {
+    Packed p;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        p.R[i] = pack16(rows[i]);
+        p.C[i] = pack16(cols[i]);
+    }
+    return p;
+}
+
+G2048_HD Packed pack_board(const Board& b) {
+    uint32_t cols[4];
+    transpose(b.r, cols);
+    return pack_board(b.r, cols);
+}
+
+// image g in 0..7 of the dihedral group: bit0 = transpose, bit1 = mirror left-right, bit2 = mirror up-down
+// (applied mirror first, transpose last).  The 8 images are the ones QAgent.update visits; its sum over them
+// does not depend on their order.
+G2048_HD Packed d4_image(const Packed& p, uint32_t g) {
+    const bool t = g & 1u, fh = g & 2u, fv = g & 4u;
+    Packed q;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        uint32_t r_src = fv ? p.R[3 - i] : p.R[i];          // up-down mirror reverses the order of rows ...
+        uint32_t c_src = fh ? p.C[3 - i] : p.C[i];          // left-right mirror reverses the order of columns
+        q.R[i] = fh ? nibrev16(r_src) : r_src;              // ... and a left-right mirror reverses cells inside a row
+        q.C[i] = fv ? nibrev16(c_src) : c_src;
+    }
+    if (t) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            uint32_t tmp = q.R[i];
+            q.R[i] = q.C[i];
+            q.C[i] = tmp;
+        }
+    }
+    return q;
+}
+
+// bit-fields of the packed rows / columns
+#define G2048_CELL(p, r, c) (((p).R[r] >> (12 - 4 * (c))) & 0xFu)
+#define G2048_PAIR_R(p, r, c) (((p).R[r] >> (8 - 4 * (c))) & 0xFFu)    /* (r,c),(r,c+1) */
+#define G2048_PAIR_C(p, c, r) (((p).C[c] >> (8 - 4 * (r))) & 0xFFu)    /* (r,c),(r+1,c) */
+#define G2048_TRIP_R(p, r, c) (((p).R[r] >> (4 - 4 * (c))) & 0xFFFu)   /* (r,c),(r,c+1),(r,c+2) */
+#define G2048_TRIP_C(p, c, r) (((p).C[c] >> (4 - 4 * (r))) & 0xFFFu)   /* (r,c),(r+1,c),(r+2,c) */
+
+// Flat table slots (offset included) of every feature of one board, in the reference's feature order.
+template <int N>
+G2048_HD void feature_slots(const Packed& p, uint32_t out[Shape<N>::F]);
+
+// f_2, r_learning.py:17-20: 12 vertical pairs (r-major), 12 horizontal pairs (r-major); 256 slots each
+template <>
+G2048_HD void feature_slots<2>(const Packed& p, uint32_t out[24]) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) out[4 * r + c] = (uint32_t)(4 * r + c) * 256u + G2048_PAIR_C(p, c, r);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) out[12 + 3 * r + c] = (uint32_t)(12 + 3 * r + c) * 256u + G2048_PAIR_R(p, r, c);
+}
+
+// f_3, r_learning.py:24-31: 8 vertical triples, 8 horizontal triples, then for each 2x2 window (3x3 of them)
+// the four L-shapes; 4096 slots each
+template <>
+G2048_HD void feature_slots<3>(const Packed& p, uint32_t out[52]) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) out[4 * r + c] = (uint32_t)(4 * r + c) * 4096u + G2048_TRIP_C(p, c, r);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) out[8 + 2 * r + c] = (uint32_t)(8 + 2 * r + c) * 4096u + G2048_TRIP_R(p, r, c);
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int w = 3 * r + c;
+            uint32_t tl = G2048_CELL(p, r, c), tr = G2048_CELL(p, r, c + 1), br = G2048_CELL(p, r + 1, c + 1);
+            uint32_t bottom = G2048_PAIR_R(p, r + 1, c);            // bl, br
+            uint32_t top = G2048_PAIR_R(p, r, c);                   // tl, tr
+            uint32_t left = G2048_PAIR_C(p, c, r);                  // tl, bl
+            out[16 + w] = (uint32_t)(16 + w) * 4096u + ((bottom << 4) | tr);       // bl, br, tr  (x_ex_00)
+            out[25 + w] = (uint32_t)(25 + w) * 4096u + ((tl << 8) | bottom);       // tl, bl, br  (x_ex_01)
+            out[34 + w] = (uint32_t)(34 + w) * 4096u + ((top << 4) | br);          // tl, tr, br  (x_ex_10)
+            out[43 + w] = (uint32_t)(43 + w) * 4096u + ((left << 4) | tr);         // tl, bl, tr  (x_ex_11)
+        }
+}
+
+// the 17 four-cell features shared by f_4/f_5/f_6 (r_learning.py:40-44): 4 columns, 4 rows, 9 squares
+G2048_HD void quad_slots(const Packed& p, uint32_t out[17]) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) out[c] = (uint32_t)c * 65536u + p.C[c];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[4 + r] = (uint32_t)(4 + r) * 65536u + p.R[r];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)     // (r,c),(r+1,c),(r,c+1),(r+1,c+1)
+            out[8 + 3 * r + c] = (uint32_t)(8 + 3 * r + c) * 65536u + ((G2048_PAIR_C(p, c, r) << 8) | G2048_PAIR_C(p, c + 1, r));
+}
+
+// 4 crosses around the middle cells (r_learning.py:51-52): centre, up, left, down, right
+G2048_HD void cross_slots(const Packed& p, uint32_t out[4]) {
+#pragma unroll
+    for (int r = 1; r < 3; ++r)
+#pragma unroll
+        for (int c = 1; c < 3; ++c) {
+            uint32_t idx = (G2048_CELL(p, r, c) << 16) | (G2048_CELL(p, r - 1, c) << 12) | (G2048_CELL(p, r, c - 1) << 8) |
+                           (G2048_CELL(p, r + 1, c) << 4) | G2048_CELL(p, r, c + 1);
+            out[2 * (r - 1) + (c - 1)] = CROSS_BASE + (uint32_t)(2 * (r - 1) + (c - 1)) * 1048576u + idx;
+        }
+}
+
+// 12 six-cell features in base 14 on min(tile, 13) (r_learning.py:63-68): 6 tall 3x2 blocks, 6 wide 2x3 blocks
+G2048_HD void hex_slots(const Packed& p, uint32_t out[12]) {
+    uint32_t y[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            uint32_t v = G2048_CELL(p, r, c);
+            y[r][c] = v > 13u ? 13u : v;
+        }
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            uint32_t a = 196u * y[r][c] + 14u * y[r + 1][c] + y[r + 2][c];
+            uint32_t b = 196u * y[r][c + 1] + 14u * y[r + 1][c + 1] + y[r + 2][c + 1];
+            out[3 * r + c] = HEX_BASE + (uint32_t)(3 * r + c) * HEX_SIZE + 2744u * a + b;
+        }
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            uint32_t a = 196u * y[r][c] + 14u * y[r][c + 1] + y[r][c + 2];
+            uint32_t b = 196u * y[r + 1][c] + 14u * y[r + 1][c + 1] + y[r + 1][c + 2];
+            out[6 + 2 * r + c] = HEX_BASE + (uint32_t)(6 + 2 * r + c) * HEX_SIZE + 2744u * a + b;
+        }
+}
+
+template <>
+G2048_HD void feature_slots<4>(const Packed& p, uint32_t out[17]) { quad_slots(p, out); }
+
+template <>
+G2048_HD void feature_slots<5>(const Packed& p, uint32_t out[21]) {
+    quad_slots(p, out);
+    cross_slots(p, out + 17);
+}
+
+template <>
+G2048_HD void feature_slots<6>(const Packed& p, uint32_t out[33]) {
+    quad_slots(p, out);
+    cross_slots(p, out + 17);
+    hex_slots(p, out + 21);
+}
+
+// first slot of feature i (host-side layout queries)
+G2048_HD constexpr uint32_t feature_offset(int n, int i) {
+    switch (n) {
+        case 2: return (uint32_t)i * 256u;
+        case 3: return (uint32_t)i * 4096u;
+        case 4: return (uint32_t)i * 65536u;
+        default:
+            if (i < 17) return (uint32_t)i * 65536u;
+            if (i < 21) return CROSS_BASE + (uint32_t)(i - 17) * 1048576u;
+            return HEX_BASE + (uint32_t)(i - 21) * HEX_SIZE;
+    }
+}
+
+G2048_HD constexpr uint32_t feature_size(int n, int i) {
+    switch (n) {
+        case 2: return 256u;
+        case 3: return 4096u;
+        case 4: return 65536u;
+        default: return i < 17 ? 65536u : (i < 21 ? 1048576u : HEX_SIZE);
+    }
+}
+
+}  // namespace g2048

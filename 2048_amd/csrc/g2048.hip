@@ -1,0 +1,1061 @@
+// g2048.hip — HIP kernels (gfx950 / MI355X) and the C ABI of include/g2048.h.
+//
+// One lane = one board = one thread; a wavefront holds 64 boards, a workgroup 256.  Lane state is
+// struct-of-arrays in HBM so that every load/store is a fully coalesced wave access:
+//   boards  uint4[B]      16 B   log2 tiles, row-major (game_logic.py:62 narrowed to u8)
+//   scores  int32[B]       4 B   Game.score
+//   rng     u64[B][2]     16 B   xoroshiro128++ state (spec: 2048_amd/rng.py)
+//   prev    uint4[2][B]   16 B   `state` of QAgent.episode (r_learning.py:226,245), double-buffered so that the
+//                                step's two update records need no extra copy (see k_td_play)
+//   label   float[B]       4 B   `old_label`
+//   flags   u8[B]                HAS_PREV / DONE
+//   weights float[slots]         flat n-tuple table, feature-major, weight_signature group order
+// There is no dense contraction anywhere on this path: no MFMA.  The kernels are integer SWAR + random 4-byte
+// gathers + fp32 atomic adds; what bounds them is the memory system, not the VALU.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+#include <string>
+
+#include "../../include/g2048.h"
+#include "features.hpp"
+
+using namespace g2048;
+
+namespace {
+
+constexpr int WG = 256;
+constexpr uint8_t HAS_PREV = G2048_LANE_HAS_PREV;
+constexpr uint8_t DONE = G2048_LANE_DONE;
+
+__device__ __forceinline__ Board ld_board(const uint4* p, size_t i) {
+    uint4 v = p[i];
+    Board b;
+    b.r[0] = v.x; b.r[1] = v.y; b.r[2] = v.z; b.r[3] = v.w;
+    return b;
+}
+__device__ __forceinline__ void st_board(uint4* p, size_t i, const Board& b) { p[i] = make_uint4(b.r[0], b.r[1], b.r[2], b.r[3]); }
+__device__ __forceinline__ Rng ld_rng(const ulonglong2* p, size_t i) {
+    ulonglong2 v = p[i];
+    Rng g;
+    g.s0 = v.x; g.s1 = v.y;
+    return g;
+}
+__device__ __forceinline__ void st_rng(ulonglong2* p, size_t i, const Rng& g) { p[i] = make_ulonglong2(g.s0, g.s1); }
+
+struct Stats {   // device mirror of g2048_stats (all u64)
+    unsigned long long episodes, moves, score_sum, best_score, max_tile[20], overflow16;
+};
+static_assert(sizeof(Stats) == sizeof(g2048_stats), "stats layout");
+
+__device__ __forceinline__ void count_finished(Stats* st, const Board& b, int32_t score, bool overflow) {
+    atomicAdd(&st->episodes, 1ull);
+    atomicAdd(&st->score_sum, (unsigned long long)(score < 0 ? 0 : score));
+    atomicMax(&st->best_score, (unsigned long long)(score < 0 ? 0 : score));
+    uint32_t t = max_tile(b);
+    atomicAdd(&st->max_tile[t > 19u ? 19u : t], 1ull);
+    if (overflow) atomicAdd(&st->overflow16, 1ull);
+}
+
+// one atomic per workgroup for the number of board-steps executed
+__device__ __forceinline__ void count_moves(Stats* st, bool moved) {
+    __shared__ unsigned int wg_moves;
+    if (threadIdx.x == 0) wg_moves = 0;
+    __syncthreads();
+    unsigned long long m = __ballot(moved);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&wg_moves, (unsigned int)__popcll(m));
+    __syncthreads();
+    if (threadIdx.x == 0 && wg_moves) atomicAdd(&st->moves, (unsigned long long)wg_moves);
+}
+
+// ------------------------------------------------------------------------------------------------ lane state
+
+__global__ __launch_bounds__(WG) void k_seed(ulonglong2* rng, uint32_t B, uint64_t seed, uint64_t lane0) {
+    uint32_t i = blockIdx.x * WG + threadIdx.x;
+    if (i < B) st_rng(rng, i, seed_lane(seed, lane0 + i));
+}
+
+// Game.__init__ (game_logic.py:55-66) in every lane
+__global__ __launch_bounds__(WG) void k_new_games(uint4* boards, int32_t* scores, ulonglong2* rng, float* label, uint8_t* flags,
+                                                  uint32_t B) {
+    uint32_t i = blockIdx.x * WG + threadIdx.x;
+    if (i >= B) return;
+    Rng g = ld_rng(rng, i);
+    st_board(boards, i, new_game(g));
+    st_rng(rng, i, g);
+    scores[i] = 0;
+    label[i] = 0.0f;
+    flags[i] = 0;
+}
+
+// ------------------------------------------------------------------------------------------------ environment
+
+struct Moves4 {          // four named members, not an array: keeps every field a scalar the compiler can hold in a register
+    Moved m0, m1, m2, m3;
+};
+
+__device__ __forceinline__ Moves4 all_moves(const Board& b) {
+    uint32_t cols[4];
+    transpose(b.r, cols);
+    Moves4 r;
+    r.m0 = move_dir<0>(b.r, cols);
+    r.m1 = move_dir<1>(b.r, cols);
+    r.m2 = move_dir<2>(b.r, cols);
+    r.m3 = move_dir<3>(b.r, cols);
+    return r;
+}
+
+__device__ __forceinline__ uint8_t changed_mask(const Moves4& mv) {
+    return (uint8_t)((mv.m0.changed ? 1u : 0u) | (mv.m1.changed ? 2u : 0u) | (mv.m2.changed ? 4u : 0u) | (mv.m3.changed ? 8u : 0u));
+}
+
+// The move of direction d (runtime), blended with bit masks.  A `?:` chain here would be folded by the compiler into a
+// load through a selected stack address, which parks all four moves in scratch memory (116 B per lane).
+__device__ __forceinline__ Moved pick(const Moves4& mv, uint32_t d) {
+    const uint32_t k0 = 0u - (uint32_t)(d == 0), k1 = 0u - (uint32_t)(d == 1), k2 = 0u - (uint32_t)(d == 2), k3 = 0u - (uint32_t)(d == 3);
+#define G2048_BLEND(field) ((mv.m0.field & k0) | (mv.m1.field & k1) | (mv.m2.field & k2) | (mv.m3.field & k3))
+    Moved o;
+    o.after.r[0] = G2048_BLEND(after.r[0]);
+    o.after.r[1] = G2048_BLEND(after.r[1]);
+    o.after.r[2] = G2048_BLEND(after.r[2]);
+    o.after.r[3] = G2048_BLEND(after.r[3]);
+    o.ma = G2048_BLEND(ma);
+    o.mb = G2048_BLEND(mb);
+    o.changed = ((uint32_t)changed_mask(mv) >> d) & 1u;
+#undef G2048_BLEND
+    return o;
+}
+
+// Game.pre_move x 4 (game_logic.py:136-142)
+__global__ __launch_bounds__(WG) void k_move_all(const uint4* boards, uint32_t B, uint4* after, int4* reward, uint8_t* changed) {
+    uint32_t i = blockIdx.x * WG + threadIdx.x;
+    if (i >= B) return;
+    Moves4 mv = all_moves(ld_board(boards, i));
+    st_board(after, (size_t)i * 4 + 0, mv.m0.after);
+    st_board(after, (size_t)i * 4 + 1, mv.m1.after);
+    st_board(after, (size_t)i * 4 + 2, mv.m2.after);
+    st_board(after, (size_t)i * 4 + 3, mv.m3.after);
+    reward[i] = make_int4((int32_t)merged_score(mv.m0.ma, mv.m0.mb), (int32_t)merged_score(mv.m1.ma, mv.m1.mb),
+                          (int32_t)merged_score(mv.m2.ma, mv.m2.mb), (int32_t)merged_score(mv.m3.ma, mv.m3.mb));
+    changed[i] = changed_mask(mv);
+}
+
+// Game.make_move (game_logic.py:144-148)
+__global__ __launch_bounds__(WG) void k_apply_moves(uint4* boards, int32_t* scores, uint32_t B, const uint8_t* dirs, uint8_t* moved) {
+    uint32_t i = blockIdx.x * WG + threadIdx.x;
+    if (i >= B) return;
+    Moves4 mv = all_moves(ld_board(boards, i));
+    uint32_t d = dirs[i] & 3u;
+    Moved c = pick(mv, d);
+    st_board(boards, i, c.after);
+    scores[i] += (int32_t)merged_score(c.ma, c.mb);
+    if (moved) moved[i] = c.changed;
+}
+
+__global__ __launch_bounds__(WG) void k_terminal(const uint4* boards, uint32_t B, uint8_t* over, uint8_t* n_empty, uint8_t* n_pairs) {
+    uint32_t i = blockIdx.x * WG + threadIdx.x;
+    if (i >= B) return;
+    Board b = ld_board(boards, i);
+    over[i] = game_over(b);
+    n_empty[i] = (uint8_t)empty_count(b);
+    n_pairs[i] = (uint8_t)adjacent_pairs(b);
+}
+
+// Game.new_tile (game_logic.py:112-121): injected draws, or the lane's own stream with the draws exported
+__global__ __launch_bounds__(WG) void k_spawn(uint4* boards, ulonglong2* rng, uint32_t B, const uint8_t* in_r10, const uint8_t* in_k,
+                                              uint8_t* out_r10, uint8_t* out_k) {
+    uint32_t i = blockIdx.x * WG + threadIdx.x;
+    if (i >= B) return;
+    Board b = ld_board(boards, i);
+    uint32_t e = empty_bits(b);
+    uint32_t r10 = 255, k = 255;
+    if (e) {
+        if (in_r10) {
+            r10 = in_r10[i];
+            k = in_k[i];
+            if (k >= popcount32(e)) k = popcount32(e) - 1;      // never index past the empty list
+        } else {
+            Rng g = ld_rng(rng, i);
+            spawn_draw(next_u64(g), popcount32(e), r10, k);
+            st_rng(rng, i, g);
+        }
+        place_tile(b, r10, k, e);
+        st_board(boards, i, b);
+    }
+    if (out_r10) out_r10[i] = (uint8_t)r10;
+    if (out_k) out_k[i] = (uint8_t)k;
+}
+
+// BASELINE config 2: nsteps of {uniformly random valid direction, move, spawn, terminal check / auto-reset}
+// with the lane state held in registers for the whole launch.
+__global__ __launch_bounds__(WG) void k_step_random(uint4* boards, int32_t* scores, ulonglong2* rng, uint8_t* flags, uint32_t B,
+                                                    uint32_t nsteps, int auto_reset, Stats* stats) {
+    uint32_t i = blockIdx.x * WG + threadIdx.x;
+    const bool in = i < B;
+    Board b = {{0, 0, 0, 0}};
+    Rng g = {1, 0};
+    int32_t score = 0;
+    uint8_t fl = DONE;
+    if (in) {
+        b = ld_board(boards, i);
+        g = ld_rng(rng, i);
+        score = scores[i];
+        fl = flags[i];
+    }
+    uint32_t my_moves = 0;
+    for (uint32_t s = 0; s < nsteps; ++s) {
+        if (fl & DONE) continue;
+        Moves4 mv = all_moves(b);
+        uint32_t mask = changed_mask(mv);
+        bool over;
+        if (mask) {
+            uint32_t j = pick_draw(next_u64(g), popcount32(mask));
+            uint32_t d = kth_set_bit(mask, j);
+            Moved c = pick(mv, d);
+            b = c.after;
+            score += (int32_t)merged_score(c.ma, c.mb);
+            ++my_moves;
+            spawn(b, g);
+            over = game_over(b) || max_tile(b) >= 16u;
+        } else {
+            over = true;                                        // a dead board was loaded
+        }
+        if (over) {
+            count_finished(stats, b, score, max_tile(b) >= 16u);
+            if (auto_reset) {
+                b = new_game(g);
+                score = 0;
+            } else {
+                fl |= DONE;
+            }
+        }
+    }
+    // one moves counter update per wave
+    unsigned int w = my_moves;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) w += __shfl_down(w, off);
+    if ((threadIdx.x & 63) == 0 && w) atomicAdd(&stats->moves, (unsigned long long)w);
+    if (in) {
+        st_board(boards, i, b);
+        st_rng(rng, i, g);
+        scores[i] = score;
+        flags[i] = fl;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ features / value
+
+template <int N>
+__global__ __launch_bounds__(WG) void k_features(const uint4* boards, uint32_t B, int32_t* out) {
+    uint32_t i = blockIdx.x * WG + threadIdx.x;
+    if (i >= B) return;
+    constexpr int F = Shape<N>::F;
+    uint32_t s[F];
+    feature_slots<N>(pack_board(ld_board(boards, i)), s);
+#pragma unroll
+    for (int f = 0; f < F; ++f) out[(size_t)i * F + f] = (int32_t)(s[f] - feature_offset(N, f));
+}
+
+// QAgent.evaluate (r_learning.py:202-203): left-to-right sum of one weight per feature (fp32 here, float64 there)
+template <int N>
+__device__ __forceinline__ float value_of(const float* __restrict__ w, const Board& b) {
+    constexpr int F = Shape<N>::F;
+    uint32_t s[F];
+    feature_slots<N>(pack_board(b), s);
+    float x[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) x[f] = w[s[f]];
+    float v = 0.0f;
+#pragma unroll
+    for (int f = 0; f < F; ++f) v += x[f];
+    return v;
+}
+
+template <int N>
+__global__ __launch_bounds__(WG) void k_evaluate(const uint4* boards, uint32_t B, const float* __restrict__ w, float* value) {
+    uint32_t i = blockIdx.x * WG + threadIdx.x;
+    if (i >= B) return;
+    value[i] = value_of<N>(w, ld_board(boards, i));
+}
+
+struct Choice {
+    int action;         // -1: no direction changes the board
+    float value;
+    float v[4];
+};
+
+// greedy afterstate choice (r_learning.py:229-237): strict '>' from -inf keeps the first maximum
+template <int N>
+__device__ __forceinline__ Choice choose(const float* __restrict__ w, const Moves4& mv) {
+    Choice c;
+    c.action = -1;
+    c.value = -INFINITY;
+    int first_valid = -1;
+#define G2048_TRY_DIR(D, M)                                  \
+    c.v[D] = -INFINITY;                                      \
+    if ((M).changed) {                                       \
+        if (first_valid < 0) first_valid = D;                \
+        float v = value_of<N>(w, (M).after);                 \
+        c.v[D] = v;                                          \
+        if (v > c.value) {                                   \
+            c.value = v;                                     \
+            c.action = D;                                    \
+        }                                                    \
+    }
+    G2048_TRY_DIR(0, mv.m0)
+    G2048_TRY_DIR(1, mv.m1)
+    G2048_TRY_DIR(2, mv.m2)
+    G2048_TRY_DIR(3, mv.m3)
+#undef G2048_TRY_DIR
+    if (c.action < 0 && first_valid >= 0) {     // every value was -inf or NaN (a poisoned table): still make a legal move
+        c.action = first_valid;
+        c.value = c.v[first_valid];
+    }
+    return c;
+}
+
+template <int N>
+__global__ __launch_bounds__(WG) void k_eval_select(const uint4* boards, uint32_t B, const float* __restrict__ w, float* value,
+                                                    uint8_t* action, float4* values4) {
+    uint32_t i = blockIdx.x * WG + threadIdx.x;
+    if (i >= B) return;
+    Moves4 mv = all_moves(ld_board(boards, i));
+    Choice c = choose<N>(w, mv);
+    value[i] = c.action < 0 ? 0.0f : c.value;
+    action[i] = c.action < 0 ? (uint8_t)255 : (uint8_t)c.action;
+    if (values4) values4[i] = make_float4(c.v[0], c.v[1], c.v[2], c.v[3]);
+}
+
+// ------------------------------------------------------------------------------------------------ learning
+
+// QAgent.update (r_learning.py:207-214), one of the 8 images: += dw at every feature slot
+template <int N>
+__device__ __forceinline__ void scatter_image(float* w, const Board& state, uint32_t g, float dw) {
+    constexpr int F = Shape<N>::F;
+    uint32_t s[F];
+    feature_slots<N>(d4_image(pack_board(state), g), s);
+#pragma unroll
+    for (int f = 0; f < F; ++f) __hip_atomic_fetch_add(&w[s[f]], dw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// thread t handles image (t & 7) of record (t >> 3)
+template <int N>
+__global__ __launch_bounds__(WG) void k_update_records(float* w, const uint4* states, const float* dw, uint32_t count) {
+    uint32_t t = blockIdx.x * WG + threadIdx.x;
+    uint32_t rec = t >> 3;
+    if (rec >= count) return;
+    scatter_image<N>(w, ld_board(states, rec), t & 7u, dw[rec]);
+}
+
+// Step part 1 — the body of `while not game.game_over` in QAgent.episode (r_learning.py:228-246) for every live
+// lane, all reading the same table; emits up to two (state, dw) records per lane:
+//   record 1 (bit 0 of rec): state = prev[cur][i]  (the previous afterstate), dw1 = (reward + V(after) - old_label) * alpha / F
+//   record 2 (bit 1 of rec): state = prev[nxt][i]  (this step's afterstate),  dw2 = -V(after) * alpha / F   if the game ended
+// (r_learning.py:240 and :248).  Because `prev` is double-buffered both states are already in memory.
+template <int N>
+__global__ __launch_bounds__(WG) void k_td_play(uint4* boards, int32_t* scores, ulonglong2* rng, const uint4* prev_cur, uint4* prev_nxt,
+                                                float* label, uint8_t* flags, uint32_t B, const float* __restrict__ w, float alpha,
+                                                float* dw1, float* dw2, uint8_t* rec, int auto_reset, Stats* stats) {
+    constexpr float F = (float)Shape<N>::F;
+    uint32_t i = blockIdx.x * WG + threadIdx.x;
+    bool moved = false;
+    if (i < B) {
+        uint8_t fl = flags[i];
+        uint8_t r = 0;
+        if (!(fl & DONE)) {
+            Board b = ld_board(boards, i);
+            Rng g = ld_rng(rng, i);
+            int32_t score = scores[i];
+            float old_label = label[i];
+            Moves4 mv = all_moves(b);
+            Choice c = choose<N>(w, mv);
+            bool over, overflow = false;
+            Board after;
+            if (c.action >= 0) {
+                Moved ch = pick(mv, (uint32_t)c.action);
+                after = ch.after;
+                int32_t reward = (int32_t)merged_score(ch.ma, ch.mb);
+                if (fl & HAS_PREV) {
+                    dw1[i] = ((float)reward + c.value - old_label) * alpha / F;
+                    r |= 1;
+                }
+                score += reward;
+                st_board(prev_nxt, i, after);
+                old_label = c.value;
+                fl |= HAS_PREV;
+                moved = true;
+                b = after;
+                spawn(b, g);
+                overflow = max_tile(b) >= 16u;
+                over = game_over(b) || overflow;
+                if (over) {
+                    dw2[i] = -c.value * alpha / F;
+                    r |= 2;
+                }
+            } else {
+                // a dead board was loaded: the reference's loop would not run; only the terminal update remains
+                over = true;
+                st_board(prev_nxt, i, ld_board(prev_cur, i));
+                if (fl & HAS_PREV) {
+                    dw2[i] = -old_label * alpha / F;
+                    r |= 2;
+                }
+            }
+            if (over) {
+                count_finished(stats, b, score, overflow);
+                if (auto_reset) {
+                    b = new_game(g);
+                    score = 0;
+                    old_label = 0.0f;
+                    fl &= (uint8_t)~HAS_PREV;
+                } else {
+                    fl |= DONE;
+                }
+            }
+            st_board(boards, i, b);
+            st_rng(rng, i, g);
+            scores[i] = score;
+            label[i] = old_label;
+            flags[i] = fl;
+        }
+        rec[i] = r;
+    }
+    count_moves(stats, moved);
+}
+
+// Step part 2 — apply the step's records: QAgent.update for record 1 and record 2 of every lane.
+template <int N>
+__global__ __launch_bounds__(WG) void k_td_update(float* w, const uint4* prev_cur, const uint4* prev_nxt, const float* dw1,
+                                                  const float* dw2, const uint8_t* rec, uint32_t B) {
+    uint32_t t = blockIdx.x * WG + threadIdx.x;
+    uint32_t lane = t >> 3, g = t & 7u;
+    if (lane >= B) return;
+    uint8_t r = rec[lane];
+    if (r & 1) scatter_image<N>(w, ld_board(prev_cur, lane), g, dw1[lane]);
+    if (r & 2) scatter_image<N>(w, ld_board(prev_nxt, lane), g, dw2[lane]);
+}
+
+// init_weights (r_learning.py:139-149): U[0, scale) per slot, counter-based so any rank can build the same table
+__global__ __launch_bounds__(WG) void k_weights_init(float* w, uint64_t count, uint64_t seed, float scale) {
+    uint64_t i = (uint64_t)blockIdx.x * WG + threadIdx.x;
+    uint64_t stride = (uint64_t)gridDim.x * WG;
+    for (; i < count; i += stride) {
+        uint64_t x = seed + i;
+        uint64_t z = splitmix64(x);
+        w[i] = (float)(z >> 40) * (1.0f / 16777216.0f) * scale;
+    }
+}
+
+__global__ __launch_bounds__(WG) void k_delta_sub(const float* w, const float* w0, float* delta, uint64_t count) {
+    uint64_t i = (uint64_t)blockIdx.x * WG + threadIdx.x;
+    uint64_t stride = (uint64_t)gridDim.x * WG;
+    for (; i < count; i += stride) delta[i] = w[i] - w0[i];
+}
+
+__global__ __launch_bounds__(WG) void k_delta_add(float* w, float* w0, const float* delta, uint64_t count) {
+    uint64_t i = (uint64_t)blockIdx.x * WG + threadIdx.x;
+    uint64_t stride = (uint64_t)gridDim.x * WG;
+    for (; i < count; i += stride) {
+        float v = w0[i] + delta[i];
+        w[i] = v;
+        w0[i] = v;
+    }
+}
+
+}  // namespace
+
+// ================================================================================================ host side / C ABI
+
+struct g2048_ctx {
+    int device = 0;
+    uint32_t B = 0;
+    int n = 0, F = 0;
+    uint64_t slots = 0, seed = 0, lane0 = 0;
+    int auto_reset = 1;
+    int cur = 0;                        // which half of `prev` holds the current `state`
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    uint4* boards = nullptr;
+    int32_t* scores = nullptr;
+    ulonglong2* rng = nullptr;
+    uint4* prev[2] = {nullptr, nullptr};
+    float* label = nullptr;
+    uint8_t* flags = nullptr;
+    float *dw1 = nullptr, *dw2 = nullptr;
+    uint8_t* rec = nullptr;
+    float *w = nullptr, *w0 = nullptr, *delta = nullptr;
+    Stats* stats = nullptr;
+    void* scratch = nullptr;
+    size_t scratch_bytes = 0;
+    std::string err;
+};
+
+namespace {
+
+int fail(g2048_ctx* c, int code, const char* what, hipError_t e = hipSuccess) {
+    if (c) {
+        char buf[512];
+        if (e != hipSuccess)
+            snprintf(buf, sizeof buf, "%s: %s (%s)", what, hipGetErrorString(e), hipGetErrorName(e));
+        else
+            snprintf(buf, sizeof buf, "%s", what);
+        c->err = buf;
+    }
+    return code;
+}
+
+#define HIP_TRY(c, call)                                                     \
+    do {                                                                     \
+        hipError_t e_ = (call);                                              \
+        if (e_ != hipSuccess) return fail((c), G2048_ERR_HIP, #call, e_);    \
+    } while (0)
+
+#define NEED(c, cond, msg) \
+    do {                   \
+        if (!(cond)) return fail((c), G2048_ERR_ARG, msg); \
+    } while (0)
+
+#define NEED_TABLE(c) \
+    do {              \
+        if ((c)->n == 0) return fail((c), G2048_ERR_STATE, "context has no weight table (n_tuple == 0)"); \
+    } while (0)
+
+inline unsigned grid_for(uint64_t threads) { return (unsigned)((threads + WG - 1) / WG); }
+
+int bind(g2048_ctx* c) {
+    HIP_TRY(c, hipSetDevice(c->device));
+    return G2048_OK;
+}
+
+int ensure_scratch(g2048_ctx* c, size_t bytes) {
+    if (bytes <= c->scratch_bytes) return G2048_OK;
+    if (c->scratch) HIP_TRY(c, hipFree(c->scratch));
+    c->scratch = nullptr;
+    c->scratch_bytes = 0;
+    hipError_t e = hipMalloc(&c->scratch, bytes);
+    if (e != hipSuccess) return fail(c, G2048_ERR_NOMEM, "hipMalloc(scratch)", e);
+    c->scratch_bytes = bytes;
+    return G2048_OK;
+}
+
+int h2d(g2048_ctx* c, void* dst, const void* src, size_t bytes) {
+    HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return G2048_OK;
+}
+
+int d2h(g2048_ctx* c, void* dst, const void* src, size_t bytes) {
+    HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return G2048_OK;
+}
+
+int launched(g2048_ctx* c, const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(c, G2048_ERR_HIP, what, e);
+    return G2048_OK;
+}
+
+template <class T>
+int dalloc(g2048_ctx* c, T** p, size_t count) {
+    hipError_t e = hipMalloc((void**)p, count * sizeof(T));
+    if (e != hipSuccess) return fail(c, G2048_ERR_NOMEM, "hipMalloc", e);
+    return G2048_OK;
+}
+
+// dispatch on the n-tuple size
+#define BY_N(c, EXPR)                                                      \
+    switch ((c)->n) {                                                      \
+        case 2: { constexpr int N = 2; EXPR; } break;                      \
+        case 3: { constexpr int N = 3; EXPR; } break;                      \
+        case 4: { constexpr int N = 4; EXPR; } break;                      \
+        case 5: { constexpr int N = 5; EXPR; } break;                      \
+        case 6: { constexpr int N = 6; EXPR; } break;                      \
+        default: return fail((c), G2048_ERR_STATE, "bad n_tuple");         \
+    }
+
+int shape_of(int n, int* F, uint64_t* slots) {
+    switch (n) {
+        case 0: *F = 0; *slots = 0; return 0;
+        case 2: *F = Shape<2>::F; *slots = Shape<2>::SLOTS; return 0;
+        case 3: *F = Shape<3>::F; *slots = Shape<3>::SLOTS; return 0;
+        case 4: *F = Shape<4>::F; *slots = Shape<4>::SLOTS; return 0;
+        case 5: *F = Shape<5>::F; *slots = Shape<5>::SLOTS; return 0;
+        case 6: *F = Shape<6>::F; *slots = Shape<6>::SLOTS; return 0;
+        default: return -1;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int g2048_abi_version(void) { return G2048_ABI_VERSION; }
+
+const char* g2048_strerror(int s) {
+    switch (s) {
+        case G2048_OK: return "ok";
+        case G2048_ERR_ARG: return "bad argument";
+        case G2048_ERR_HIP: return "HIP runtime error";
+        case G2048_ERR_NOMEM: return "out of memory";
+        case G2048_ERR_STATE: return "invalid state for this call";
+        case G2048_ERR_NODEV: return "no usable GPU";
+        default: return "unknown status";
+    }
+}
+
+int g2048_device_count(int* count) {
+    if (!count) return G2048_ERR_ARG;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    *count = e == hipSuccess ? n : 0;
+    return G2048_OK;
+}
+
+int g2048_num_feat(int n) {
+    int F;
+    uint64_t s;
+    return shape_of(n, &F, &s) == 0 && n != 0 ? F : G2048_ERR_ARG;
+}
+
+int64_t g2048_table_slots(int n) {
+    int F;
+    uint64_t s;
+    return shape_of(n, &F, &s) == 0 && n != 0 ? (int64_t)s : (int64_t)G2048_ERR_ARG;
+}
+
+int g2048_feature_layout(int n, int64_t* offsets, int64_t* sizes) {
+    int F;
+    uint64_t s;
+    if (shape_of(n, &F, &s) != 0 || n == 0) return G2048_ERR_ARG;
+    for (int i = 0; i < F; ++i) {
+        if (offsets) offsets[i] = feature_offset(n, i);
+        if (sizes) sizes[i] = feature_size(n, i);
+    }
+    return G2048_OK;
+}
+
+const char* g2048_last_error(const g2048_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int g2048_destroy(g2048_ctx* c) {
+    if (!c) return G2048_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    void* bufs[] = {c->boards, c->scores, c->rng, c->prev[0], c->prev[1], c->label, c->flags, c->dw1, c->dw2,
+                    c->rec,    c->w,      c->w0,  c->delta,   c->stats,   c->scratch};
+    for (void* p : bufs)
+        if (p) (void)hipFree(p);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return G2048_OK;
+}
+
+int g2048_create(int device, uint32_t batch, int n_tuple, uint64_t seed, uint64_t lane0, g2048_ctx** out) {
+    if (!out) return G2048_ERR_ARG;
+    *out = nullptr;
+    int F;
+    uint64_t slots;
+    if (batch == 0 || batch > (1u << 28) || shape_of(n_tuple, &F, &slots) != 0) return G2048_ERR_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return G2048_ERR_NODEV;
+    if (device < 0 || device >= ndev) return G2048_ERR_ARG;
+    g2048_ctx* c = new (std::nothrow) g2048_ctx;
+    if (!c) return G2048_ERR_NOMEM;
+    c->device = device;
+    c->B = batch;
+    c->n = n_tuple;
+    c->F = F;
+    c->slots = slots;
+    c->seed = seed;
+    c->lane0 = lane0;
+    int rc = G2048_OK;
+    auto bail = [&](int code) {
+        // keep the message readable after the context is gone
+        static thread_local std::string last;
+        last = c->err;
+        fprintf(stderr, "g2048_create: %s\n", last.c_str());
+        g2048_destroy(c);
+        return code;
+    };
+    if (hipSetDevice(device) != hipSuccess) return bail(G2048_ERR_HIP);
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail(G2048_ERR_HIP);
+    if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) return bail(G2048_ERR_HIP);
+    const size_t B = batch;
+    if ((rc = dalloc(c, &c->boards, B)) || (rc = dalloc(c, &c->scores, B)) || (rc = dalloc(c, &c->rng, B)) ||
+        (rc = dalloc(c, &c->prev[0], B)) || (rc = dalloc(c, &c->prev[1], B)) || (rc = dalloc(c, &c->label, B)) ||
+        (rc = dalloc(c, &c->flags, B)) || (rc = dalloc(c, &c->dw1, B)) || (rc = dalloc(c, &c->dw2, B)) || (rc = dalloc(c, &c->rec, B)) ||
+        (rc = dalloc(c, &c->stats, 1)))
+        return bail(rc);
+    if (slots && (rc = dalloc(c, &c->w, slots))) return bail(rc);
+    if (hipMemsetAsync(c->stats, 0, sizeof(Stats), c->stream) != hipSuccess ||
+        hipMemsetAsync(c->prev[0], 0, B * sizeof(uint4), c->stream) != hipSuccess ||
+        hipMemsetAsync(c->prev[1], 0, B * sizeof(uint4), c->stream) != hipSuccess ||
+        hipMemsetAsync(c->rec, 0, B, c->stream) != hipSuccess ||
+        (slots && hipMemsetAsync(c->w, 0, slots * sizeof(float), c->stream) != hipSuccess))
+        return bail(G2048_ERR_HIP);
+    k_seed<<<grid_for(B), WG, 0, c->stream>>>(c->rng, batch, seed, lane0);
+    k_new_games<<<grid_for(B), WG, 0, c->stream>>>(c->boards, c->scores, c->rng, c->label, c->flags, batch);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) {
+        c->err = "initial kernels failed";
+        return bail(G2048_ERR_HIP);
+    }
+    *out = c;
+    return G2048_OK;
+}
+
+int g2048_sync(g2048_ctx* c) {
+    if (!c) return G2048_ERR_ARG;
+    if (int rc = bind(c)) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return G2048_OK;
+}
+
+int g2048_timer_start(g2048_ctx* c) {
+    if (!c) return G2048_ERR_ARG;
+    if (int rc = bind(c)) return rc;
+    HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+    return G2048_OK;
+}
+
+int g2048_timer_stop(g2048_ctx* c, float* ms) {
+    if (!c || !ms) return G2048_ERR_ARG;
+    if (int rc = bind(c)) return rc;
+    HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(c, hipEventSynchronize(c->ev1));
+    HIP_TRY(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return G2048_OK;
+}
+
+#define IO_PAIR(name, field, type, per)                                                            \
+    int g2048_set_##name(g2048_ctx* c, const type* src) {                                          \
+        if (!c || !src) return c ? fail(c, G2048_ERR_ARG, "null buffer") : G2048_ERR_ARG;          \
+        if (int rc = bind(c)) return rc;                                                           \
+        return h2d(c, c->field, src, (size_t)c->B * (per) * sizeof(type));                         \
+    }                                                                                              \
+    int g2048_get_##name(g2048_ctx* c, type* dst) {                                                \
+        if (!c || !dst) return c ? fail(c, G2048_ERR_ARG, "null buffer") : G2048_ERR_ARG;          \
+        if (int rc = bind(c)) return rc;                                                           \
+        return d2h(c, dst, c->field, (size_t)c->B * (per) * sizeof(type));                         \
+    }
+
+IO_PAIR(boards, boards, uint8_t, 16)
+IO_PAIR(scores, scores, int32_t, 1)
+IO_PAIR(rng, rng, uint64_t, 2)
+
+int g2048_get_carry(g2048_ctx* c, uint8_t* prev, float* label, uint8_t* flags) {
+    if (!c) return G2048_ERR_ARG;
+    if (int rc = bind(c)) return rc;
+    int rc = G2048_OK;
+    if (prev && (rc = d2h(c, prev, c->prev[c->cur], (size_t)c->B * 16))) return rc;
+    if (label && (rc = d2h(c, label, c->label, (size_t)c->B * 4))) return rc;
+    if (flags && (rc = d2h(c, flags, c->flags, (size_t)c->B))) return rc;
+    return rc;
+}
+
+int g2048_clear_carry(g2048_ctx* c) {
+    if (!c) return G2048_ERR_ARG;
+    if (int rc = bind(c)) return rc;
+    HIP_TRY(c, hipMemsetAsync(c->flags, 0, c->B, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->label, 0, (size_t)c->B * 4, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->rec, 0, c->B, c->stream));
+    return G2048_OK;
+}
+
+int g2048_reset(g2048_ctx* c) {
+    if (!c) return G2048_ERR_ARG;
+    if (int rc = bind(c)) return rc;
+    k_new_games<<<grid_for(c->B), WG, 0, c->stream>>>(c->boards, c->scores, c->rng, c->label, c->flags, c->B);
+    return launched(c, "k_new_games");
+}
+
+int g2048_set_auto_reset(g2048_ctx* c, int on) {
+    if (!c) return G2048_ERR_ARG;
+    c->auto_reset = on ? 1 : 0;
+    return G2048_OK;
+}
+
+int g2048_move_all(g2048_ctx* c, uint8_t* after, int32_t* reward, uint8_t* changed) {
+    if (!c || !after || !reward || !changed) return c ? fail(c, G2048_ERR_ARG, "null buffer") : G2048_ERR_ARG;
+    if (int rc = bind(c)) return rc;
+    const size_t B = c->B;
+    if (int rc = ensure_scratch(c, B * (64 + 16 + 1))) return rc;
+    uint4* d_after = (uint4*)c->scratch;
+    int4* d_reward = (int4*)((char*)c->scratch + B * 64);
+    uint8_t* d_changed = (uint8_t*)c->scratch + B * 80;
+    k_move_all<<<grid_for(B), WG, 0, c->stream>>>(c->boards, c->B, d_after, d_reward, d_changed);
+    if (int rc = launched(c, "k_move_all")) return rc;
+    int rc;
+    if ((rc = d2h(c, after, d_after, B * 64)) || (rc = d2h(c, reward, d_reward, B * 16)) || (rc = d2h(c, changed, d_changed, B))) return rc;
+    return G2048_OK;
+}
+
+int g2048_apply_moves(g2048_ctx* c, const uint8_t* dirs, uint8_t* moved) {
+    if (!c || !dirs) return c ? fail(c, G2048_ERR_ARG, "null buffer") : G2048_ERR_ARG;
+    if (int rc = bind(c)) return rc;
+    const size_t B = c->B;
+    if (int rc = ensure_scratch(c, 2 * B)) return rc;
+    uint8_t* d_dirs = (uint8_t*)c->scratch;
+    uint8_t* d_moved = d_dirs + B;
+    if (int rc = h2d(c, d_dirs, dirs, B)) return rc;
+    k_apply_moves<<<grid_for(B), WG, 0, c->stream>>>(c->boards, c->scores, c->B, d_dirs, d_moved);
+    if (int rc = launched(c, "k_apply_moves")) return rc;
+    if (moved) return d2h(c, moved, d_moved, B);
+    return G2048_OK;
+}
+
+int g2048_terminal(g2048_ctx* c, uint8_t* over, uint8_t* n_empty, uint8_t* n_pairs) {
+    if (!c) return G2048_ERR_ARG;
+    if (int rc = bind(c)) return rc;
+    const size_t B = c->B;
+    if (int rc = ensure_scratch(c, 3 * B)) return rc;
+    uint8_t* d = (uint8_t*)c->scratch;
+    k_terminal<<<grid_for(B), WG, 0, c->stream>>>(c->boards, c->B, d, d + B, d + 2 * B);
+    if (int rc = launched(c, "k_terminal")) return rc;
+    int rc;
+    if (over && (rc = d2h(c, over, d, B))) return rc;
+    if (n_empty && (rc = d2h(c, n_empty, d + B, B))) return rc;
+    if (n_pairs && (rc = d2h(c, n_pairs, d + 2 * B, B))) return rc;
+    return g2048_sync(c);
+}
+
+static int spawn_impl(g2048_ctx* c, const uint8_t* in_r10, const uint8_t* in_k, uint8_t* out_r10, uint8_t* out_k) {
+    if (int rc = bind(c)) return rc;
+    const size_t B = c->B;
+    if (int rc = ensure_scratch(c, 4 * B)) return rc;
+    uint8_t* d = (uint8_t*)c->scratch;
+    if (in_r10) {
+        int rc;
+        if ((rc = h2d(c, d, in_r10, B)) || (rc = h2d(c, d + B, in_k, B))) return rc;
+    }
+    k_spawn<<<grid_for(B), WG, 0, c->stream>>>(c->boards, c->rng, c->B, in_r10 ? d : nullptr, in_r10 ? d + B : nullptr, d + 2 * B, d + 3 * B);
+    if (int rc = launched(c, "k_spawn")) return rc;
+    int rc;
+    if (out_r10 && (rc = d2h(c, out_r10, d + 2 * B, B))) return rc;
+    if (out_k && (rc = d2h(c, out_k, d + 3 * B, B))) return rc;
+    return G2048_OK;
+}
+
+int g2048_spawn(g2048_ctx* c, uint8_t* r10, uint8_t* k) {
+    if (!c) return G2048_ERR_ARG;
+    return spawn_impl(c, nullptr, nullptr, r10, k);
+}
+
+int g2048_spawn_injected(g2048_ctx* c, const uint8_t* r10, const uint8_t* k) {
+    if (!c || !r10 || !k) return c ? fail(c, G2048_ERR_ARG, "null buffer") : G2048_ERR_ARG;
+    return spawn_impl(c, r10, k, nullptr, nullptr);
+}
+
+int g2048_step_random(g2048_ctx* c, uint32_t nsteps) {
+    if (!c) return G2048_ERR_ARG;
+    if (int rc = bind(c)) return rc;
+    k_step_random<<<grid_for(c->B), WG, 0, c->stream>>>(c->boards, c->scores, c->rng, c->flags, c->B, nsteps, c->auto_reset, c->stats);
+    return launched(c, "k_step_random");
+}
+
+int g2048_features(g2048_ctx* c, int32_t* out) {
+    if (!c || !out) return c ? fail(c, G2048_ERR_ARG, "null buffer") : G2048_ERR_ARG;
+    NEED_TABLE(c);
+    if (int rc = bind(c)) return rc;
+    const size_t bytes = (size_t)c->B * c->F * 4;
+    if (int rc = ensure_scratch(c, bytes)) return rc;
+    BY_N(c, (k_features<N><<<grid_for(c->B), WG, 0, c->stream>>>(c->boards, c->B, (int32_t*)c->scratch)));
+    if (int rc = launched(c, "k_features")) return rc;
+    return d2h(c, out, c->scratch, bytes);
+}
+
+int g2048_weights_set(g2048_ctx* c, const float* w, int64_t count) {
+    if (!c || !w) return c ? fail(c, G2048_ERR_ARG, "null buffer") : G2048_ERR_ARG;
+    NEED_TABLE(c);
+    NEED(c, count == (int64_t)c->slots, "weight count does not match the table");
+    if (int rc = bind(c)) return rc;
+    return h2d(c, c->w, w, c->slots * 4);
+}
+
+int g2048_weights_get(g2048_ctx* c, float* w, int64_t count) {
+    if (!c || !w) return c ? fail(c, G2048_ERR_ARG, "null buffer") : G2048_ERR_ARG;
+    NEED_TABLE(c);
+    NEED(c, count == (int64_t)c->slots, "weight count does not match the table");
+    if (int rc = bind(c)) return rc;
+    return d2h(c, w, c->w, c->slots * 4);
+}
+
+int g2048_weights_init(g2048_ctx* c, uint64_t seed, float scale) {
+    if (!c) return G2048_ERR_ARG;
+    NEED_TABLE(c);
+    if (int rc = bind(c)) return rc;
+    k_weights_init<<<2048, WG, 0, c->stream>>>(c->w, c->slots, seed, scale);
+    return launched(c, "k_weights_init");
+}
+
+int g2048_evaluate(g2048_ctx* c, float* value) {
+    if (!c || !value) return c ? fail(c, G2048_ERR_ARG, "null buffer") : G2048_ERR_ARG;
+    NEED_TABLE(c);
+    if (int rc = bind(c)) return rc;
+    if (int rc = ensure_scratch(c, (size_t)c->B * 4)) return rc;
+    BY_N(c, (k_evaluate<N><<<grid_for(c->B), WG, 0, c->stream>>>(c->boards, c->B, c->w, (float*)c->scratch)));
+    if (int rc = launched(c, "k_evaluate")) return rc;
+    return d2h(c, value, c->scratch, (size_t)c->B * 4);
+}
+
+int g2048_eval_select(g2048_ctx* c, float* value, uint8_t* action, float* values4) {
+    if (!c || !value || !action) return c ? fail(c, G2048_ERR_ARG, "null buffer") : G2048_ERR_ARG;
+    NEED_TABLE(c);
+    if (int rc = bind(c)) return rc;
+    const size_t B = c->B;
+    if (int rc = ensure_scratch(c, B * (16 + 4 + 1))) return rc;
+    float4* d_v4 = (float4*)c->scratch;
+    float* d_v = (float*)((char*)c->scratch + B * 16);
+    uint8_t* d_a = (uint8_t*)c->scratch + B * 20;
+    BY_N(c, (k_eval_select<N><<<grid_for(B), WG, 0, c->stream>>>(c->boards, c->B, c->w, d_v, d_a, values4 ? d_v4 : nullptr)));
+    if (int rc = launched(c, "k_eval_select")) return rc;
+    int rc;
+    if ((rc = d2h(c, value, d_v, B * 4)) || (rc = d2h(c, action, d_a, B))) return rc;
+    if (values4 && (rc = d2h(c, values4, d_v4, B * 16))) return rc;
+    return G2048_OK;
+}
+
+int g2048_update(g2048_ctx* c, const uint8_t* states, const float* dw, int64_t count) {
+    if (!c || !states || !dw) return c ? fail(c, G2048_ERR_ARG, "null buffer") : G2048_ERR_ARG;
+    NEED_TABLE(c);
+    NEED(c, count >= 0 && count <= (1 << 28), "bad record count");
+    if (count == 0) return G2048_OK;
+    if (int rc = bind(c)) return rc;
+    const size_t n = (size_t)count;
+    if (int rc = ensure_scratch(c, n * 20)) return rc;
+    uint4* d_states = (uint4*)c->scratch;
+    float* d_dw = (float*)((char*)c->scratch + n * 16);
+    int rc;
+    if ((rc = h2d(c, d_states, states, n * 16)) || (rc = h2d(c, d_dw, dw, n * 4))) return rc;
+    BY_N(c, (k_update_records<N><<<grid_for(n * 8), WG, 0, c->stream>>>(c->w, d_states, d_dw, (uint32_t)n)));
+    if ((rc = launched(c, "k_update_records"))) return rc;
+    return g2048_sync(c);
+}
+
+int g2048_td_steps(g2048_ctx* c, float alpha, uint32_t nsteps) {
+    if (!c) return G2048_ERR_ARG;
+    NEED_TABLE(c);
+    if (int rc = bind(c)) return rc;
+    const uint32_t B = c->B;
+    for (uint32_t s = 0; s < nsteps; ++s) {
+        uint4* pc = c->prev[c->cur];
+        uint4* pn = c->prev[c->cur ^ 1];
+        BY_N(c, (k_td_play<N><<<grid_for(B), WG, 0, c->stream>>>(c->boards, c->scores, c->rng, pc, pn, c->label, c->flags, B, c->w, alpha,
+                                                                 c->dw1, c->dw2, c->rec, c->auto_reset, c->stats)));
+        BY_N(c, (k_td_update<N><<<grid_for((uint64_t)B * 8), WG, 0, c->stream>>>(c->w, pc, pn, c->dw1, c->dw2, c->rec, B)));
+        c->cur ^= 1;
+    }
+    return launched(c, "k_td_play/k_td_update");
+}
+
+int g2048_td_steps_profiled(g2048_ctx* c, float alpha, uint32_t nsteps, float* ms_play, float* ms_update) {
+    if (!c || !ms_play || !ms_update) return c ? fail(c, G2048_ERR_ARG, "null buffer") : G2048_ERR_ARG;
+    NEED_TABLE(c);
+    if (int rc = bind(c)) return rc;
+    const uint32_t B = c->B;
+    hipEvent_t e[3];
+    for (auto& ev : e) HIP_TRY(c, hipEventCreate(&ev));
+    double tp = 0, tu = 0;
+    int rc = G2048_OK;
+    for (uint32_t s = 0; s < nsteps && rc == G2048_OK; ++s) {
+        uint4* pc = c->prev[c->cur];
+        uint4* pn = c->prev[c->cur ^ 1];
+        (void)hipEventRecord(e[0], c->stream);
+        BY_N(c, (k_td_play<N><<<grid_for(B), WG, 0, c->stream>>>(c->boards, c->scores, c->rng, pc, pn, c->label, c->flags, B, c->w, alpha,
+                                                                 c->dw1, c->dw2, c->rec, c->auto_reset, c->stats)));
+        (void)hipEventRecord(e[1], c->stream);
+        BY_N(c, (k_td_update<N><<<grid_for((uint64_t)B * 8), WG, 0, c->stream>>>(c->w, pc, pn, c->dw1, c->dw2, c->rec, B)));
+        (void)hipEventRecord(e[2], c->stream);
+        c->cur ^= 1;
+        float a = 0, b = 0;
+        if (hipEventSynchronize(e[2]) != hipSuccess || hipEventElapsedTime(&a, e[0], e[1]) != hipSuccess ||
+            hipEventElapsedTime(&b, e[1], e[2]) != hipSuccess)
+            rc = fail(c, G2048_ERR_HIP, "event timing failed");
+        tp += a;
+        tu += b;
+    }
+    for (auto& ev : e) (void)hipEventDestroy(ev);
+    if (rc) return rc;
+    *ms_play = nsteps ? (float)(tp / nsteps) : 0.0f;
+    *ms_update = nsteps ? (float)(tu / nsteps) : 0.0f;
+    return launched(c, "k_td_play/k_td_update");
+}
+
+int g2048_stats_get(g2048_ctx* c, g2048_stats* out) {
+    if (!c || !out) return G2048_ERR_ARG;
+    if (int rc = bind(c)) return rc;
+    return d2h(c, out, c->stats, sizeof(Stats));
+}
+
+int g2048_stats_reset(g2048_ctx* c) {
+    if (!c) return G2048_ERR_ARG;
+    if (int rc = bind(c)) return rc;
+    HIP_TRY(c, hipMemsetAsync(c->stats, 0, sizeof(Stats), c->stream));
+    return G2048_OK;
+}
+
+int g2048_weights_device_ptr(g2048_ctx* c, void** ptr, int64_t* count) {
+    if (!c || !ptr) return G2048_ERR_ARG;
+    NEED_TABLE(c);
+    *ptr = c->w;
+    if (count) *count = (int64_t)c->slots;
+    return G2048_OK;
+}
+
+static int ensure_delta(g2048_ctx* c) {
+    int rc;
+    if (!c->w0 && (rc = dalloc(c, &c->w0, c->slots))) return rc;
+    if (!c->delta && (rc = dalloc(c, &c->delta, c->slots))) return rc;
+    return G2048_OK;
+}
+
+int g2048_delta_begin(g2048_ctx* c) {
+    if (!c) return G2048_ERR_ARG;
+    NEED_TABLE(c);
+    if (int rc = bind(c)) return rc;
+    if (int rc = ensure_delta(c)) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->w0, c->w, c->slots * 4, hipMemcpyDeviceToDevice, c->stream));
+    return G2048_OK;
+}
+
+int g2048_delta_extract(g2048_ctx* c, void* dst) {
+    if (!c) return G2048_ERR_ARG;
+    NEED_TABLE(c);
+    if (!c->w0) return fail(c, G2048_ERR_STATE, "g2048_delta_begin was not called");
+    if (int rc = bind(c)) return rc;
+    k_delta_sub<<<2048, WG, 0, c->stream>>>(c->w, c->w0, dst ? (float*)dst : c->delta, c->slots);
+    if (int rc = launched(c, "k_delta_sub")) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return G2048_OK;
+}
+
+int g2048_delta_apply(g2048_ctx* c, const void* src) {
+    if (!c) return G2048_ERR_ARG;
+    NEED_TABLE(c);
+    if (!c->w0) return fail(c, G2048_ERR_STATE, "g2048_delta_begin was not called");
+    if (int rc = bind(c)) return rc;
+    k_delta_add<<<2048, WG, 0, c->stream>>>(c->w, c->w0, src ? (const float*)src : c->delta, c->slots);
+    if (int rc = launched(c, "k_delta_add")) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return G2048_OK;
+}
+
+int g2048_delta_device_ptr(g2048_ctx* c, void** ptr) {
+    if (!c || !ptr) return G2048_ERR_ARG;
+    NEED_TABLE(c);
+    if (int rc = bind(c)) return rc;
+    if (int rc = ensure_delta(c)) return rc;
+    *ptr = c->delta;
+    return G2048_OK;
+}
+
+int g2048_stream_handle(g2048_ctx* c, void** s) {
+    if (!c || !s) return G2048_ERR_ARG;
+    *s = (void*)c->stream;
+    return G2048_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,217 @@
+"""Engine — a NumPy-facing handle on one g2048 device context (one GPU, one batch of lanes).
+
+Thin by design: every method is one C-ABI call (include/g2048.h) plus buffer plumbing.  The
+reference-shaped classes (`Game`, `QAgent`) in game_logic.py / r_learning.py are built on it.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import check
+
+NUM_FEAT = {2: 24, 3: 52, 4: 17, 5: 21, 6: 33}              # QAgent.parameter_shape, r_learning.py:88
+
+
+def _buf(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def table_slots(n):
+    return int(_lib.load().g2048_table_slots(n))
+
+
+def feature_layout(n):
+    F = NUM_FEAT[n]
+    offs = np.zeros(F, np.int64)
+    sizes = np.zeros(F, np.int64)
+    check(_lib.load().g2048_feature_layout(n, _buf(offs), _buf(sizes)))
+    return offs, sizes
+
+
+class Engine:
+    def __init__(self, batch, n=0, seed=2048, lane0=0, device=0):
+        self.lib = _lib.load()
+        self.batch, self.n, self.seed, self.lane0, self.device = int(batch), int(n), int(seed), int(lane0), int(device)
+        self.num_feat = NUM_FEAT.get(self.n, 0)
+        self.slots = table_slots(self.n) if self.n else 0
+        ctx = ctypes.c_void_p()
+        check(self.lib.g2048_create(self.device, self.batch, self.n, self.seed & (2 ** 64 - 1), self.lane0, ctypes.byref(ctx)))
+        self.ctx = ctx
+
+    def close(self):
+        if getattr(self, 'ctx', None):
+            self.lib.g2048_destroy(self.ctx)
+            self.ctx = None
+
+    __del__ = close
+
+    def _c(self, status):
+        check(status, self.ctx)
+
+    # ---- lane state
+    def set_boards(self, boards, clear_carry=True):
+        b = np.ascontiguousarray(np.asarray(boards).reshape(self.batch, 16), np.uint8)
+        self._c(self.lib.g2048_set_boards(self.ctx, _buf(b)))
+        if clear_carry:
+            self._c(self.lib.g2048_clear_carry(self.ctx))
+
+    def get_boards(self):
+        b = np.empty((self.batch, 4, 4), np.uint8)
+        self._c(self.lib.g2048_get_boards(self.ctx, _buf(b)))
+        return b
+
+    def set_scores(self, scores):
+        s = np.ascontiguousarray(scores, np.int32).reshape(self.batch)
+        self._c(self.lib.g2048_set_scores(self.ctx, _buf(s)))
+
+    def get_scores(self):
+        s = np.empty(self.batch, np.int32)
+        self._c(self.lib.g2048_get_scores(self.ctx, _buf(s)))
+        return s
+
+    def set_rng(self, state):
+        s = np.ascontiguousarray(state, np.uint64).reshape(self.batch, 2)
+        self._c(self.lib.g2048_set_rng(self.ctx, _buf(s)))
+
+    def get_rng(self):
+        s = np.empty((self.batch, 2), np.uint64)
+        self._c(self.lib.g2048_get_rng(self.ctx, _buf(s)))
+        return s
+
+    def get_carry(self):
+        prev = np.empty((self.batch, 4, 4), np.uint8)
+        label = np.empty(self.batch, np.float32)
+        flags = np.empty(self.batch, np.uint8)
+        self._c(self.lib.g2048_get_carry(self.ctx, _buf(prev), _buf(label), _buf(flags)))
+        return prev, label, flags
+
+    def clear_carry(self):
+        self._c(self.lib.g2048_clear_carry(self.ctx))
+
+    def reset(self):
+        self._c(self.lib.g2048_reset(self.ctx))
+
+    def set_auto_reset(self, on):
+        self._c(self.lib.g2048_set_auto_reset(self.ctx, int(bool(on))))
+
+    def sync(self):
+        self._c(self.lib.g2048_sync(self.ctx))
+
+    # ---- environment
+    def move_all(self):
+        after = np.empty((self.batch, 4, 4, 4), np.uint8)
+        reward = np.empty((self.batch, 4), np.int32)
+        changed = np.empty(self.batch, np.uint8)
+        self._c(self.lib.g2048_move_all(self.ctx, _buf(after), _buf(reward), _buf(changed)))
+        return after, reward, changed
+
+    def apply_moves(self, dirs):
+        d = np.ascontiguousarray(dirs, np.uint8).reshape(self.batch)
+        moved = np.empty(self.batch, np.uint8)
+        self._c(self.lib.g2048_apply_moves(self.ctx, _buf(d), _buf(moved)))
+        return moved.astype(bool)
+
+    def terminal(self):
+        over, ne, npairs = (np.empty(self.batch, np.uint8) for _ in range(3))
+        self._c(self.lib.g2048_terminal(self.ctx, _buf(over), _buf(ne), _buf(npairs)))
+        return over.astype(bool), ne, npairs
+
+    def spawn(self):
+        r10 = np.empty(self.batch, np.uint8)
+        k = np.empty(self.batch, np.uint8)
+        self._c(self.lib.g2048_spawn(self.ctx, _buf(r10), _buf(k)))
+        return r10, k
+
+    def spawn_injected(self, r10, k):
+        r = np.ascontiguousarray(r10, np.uint8).reshape(self.batch)
+        kk = np.ascontiguousarray(k, np.uint8).reshape(self.batch)
+        self._c(self.lib.g2048_spawn_injected(self.ctx, _buf(r), _buf(kk)))
+
+    def step_random(self, nsteps):
+        self._c(self.lib.g2048_step_random(self.ctx, int(nsteps)))
+
+    # ---- features / value
+    def features(self):
+        out = np.empty((self.batch, self.num_feat), np.int32)
+        self._c(self.lib.g2048_features(self.ctx, _buf(out)))
+        return out
+
+    def set_weights(self, w):
+        w = np.ascontiguousarray(w, np.float32).reshape(-1)
+        self._c(self.lib.g2048_weights_set(self.ctx, _buf(w), w.size))
+
+    def get_weights(self):
+        w = np.empty(self.slots, np.float32)
+        self._c(self.lib.g2048_weights_get(self.ctx, _buf(w), w.size))
+        return w
+
+    def init_weights(self, seed=0, scale=0.01):
+        self._c(self.lib.g2048_weights_init(self.ctx, int(seed) & (2 ** 64 - 1), float(scale)))
+
+    def evaluate(self):
+        v = np.empty(self.batch, np.float32)
+        self._c(self.lib.g2048_evaluate(self.ctx, _buf(v)))
+        return v
+
+    def eval_select(self, want_all=False):
+        v = np.empty(self.batch, np.float32)
+        a = np.empty(self.batch, np.uint8)
+        v4 = np.empty((self.batch, 4), np.float32) if want_all else None
+        self._c(self.lib.g2048_eval_select(self.ctx, _buf(v), _buf(a), _buf(v4) if want_all else None))
+        return (v, a, v4) if want_all else (v, a)
+
+    # ---- learning
+    def update(self, states, dw):
+        s = np.ascontiguousarray(np.asarray(states).reshape(-1, 16), np.uint8)
+        d = np.ascontiguousarray(dw, np.float32).reshape(-1)
+        assert len(s) == len(d)
+        self._c(self.lib.g2048_update(self.ctx, _buf(s), _buf(d), len(d)))
+
+    def td_steps(self, alpha, nsteps=1):
+        self._c(self.lib.g2048_td_steps(self.ctx, float(alpha), int(nsteps)))
+
+    def stats(self):
+        st = _lib.Stats()
+        self._c(self.lib.g2048_stats_get(self.ctx, ctypes.byref(st)))
+        return dict(episodes=st.episodes, moves=st.moves, score_sum=st.score_sum, best_score=st.best_score,
+                    max_tile=list(st.max_tile), overflow16=st.overflow16)
+
+    def stats_reset(self):
+        self._c(self.lib.g2048_stats_reset(self.ctx))
+
+    # ---- timing (HIP events on the context's own stream)
+    def timer_start(self):
+        self._c(self.lib.g2048_timer_start(self.ctx))
+
+    def timer_stop(self):
+        ms = ctypes.c_float()
+        self._c(self.lib.g2048_timer_stop(self.ctx, ctypes.byref(ms)))
+        return ms.value
+
+    # ---- multi-GPU plumbing
+    def weights_ptr(self):
+        p, n = ctypes.c_void_p(), ctypes.c_int64()
+        self._c(self.lib.g2048_weights_device_ptr(self.ctx, ctypes.byref(p), ctypes.byref(n)))
+        return p.value, n.value
+
+    def delta_begin(self):
+        self._c(self.lib.g2048_delta_begin(self.ctx))
+
+    def delta_extract(self, dst_ptr=None):
+        """delta = W - W0 into the device buffer at dst_ptr (e.g. tensor.data_ptr()) or the context's own."""
+        self._c(self.lib.g2048_delta_extract(self.ctx, ctypes.c_void_p(dst_ptr)))
+
+    def delta_apply(self, src_ptr=None):
+        self._c(self.lib.g2048_delta_apply(self.ctx, ctypes.c_void_p(src_ptr)))
+
+    def delta_ptr(self):
+        p = ctypes.c_void_p()
+        self._c(self.lib.g2048_delta_device_ptr(self.ctx, ctypes.byref(p)))
+        return p.value
+
+    def td_steps_profiled(self, alpha, nsteps):
+        """(ms per k_td_play launch, ms per k_td_update launch), HIP events on the context's stream."""
+        a, b = ctypes.c_float(), ctypes.c_float()
+        self._c(self.lib.g2048_td_steps_profiled(self.ctx, float(alpha), int(nsteps), ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value

@@ -1,0 +1,135 @@
+/* g2048.h — C ABI of the MI355X-native batched 2048 environment + n-tuple TD(0) learner.
+ *
+ * The reference (abachurin/2048) has no FFI: its hot path sits behind two Python classes, `Game`
+ * (game2048/game_logic.py) and `QAgent` (game2048/r_learning.py).  Each entry point below names the
+ * reference code it replaces; INTEGRATION.md shows the ctypes binding a maintainer adds on the Python side.
+ *
+ * Conventions
+ *   - every function returns an int status: 0 = G2048_OK, negative = error (g2048_strerror / g2048_last_error);
+ *     nothing throws or aborts across the boundary;
+ *   - host buffers are caller-owned plain arrays, copied synchronously; sizes are implied by the context
+ *     (B = batch, F = g2048_num_feat(n)) unless a count is passed;
+ *   - a board is 16 uint8 log2-tiles, row-major (0 = empty, k = tile 2^k), i.e. game_logic.py:62 narrowed to u8;
+ *   - directions: 0 left, 1 up, 2 right, 3 down (Game.actions, game_logic.py:50);
+ *   - a context owns all device memory and one HIP stream; it is not re-entrant (the caller serialises calls
+ *     on one context); distinct contexts are independent.  ctypes releases the GIL around every call.
+ *   - there is NO CPU implementation behind this ABI: g2048_create fails with G2048_ERR_NODEV without a GPU.
+ */
+#ifndef G2048_H
+#define G2048_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define G2048_ABI_VERSION 1
+
+enum {
+    G2048_OK = 0,
+    G2048_ERR_ARG = -1,    /* bad argument (null pointer, bad n-tuple, count mismatch) */
+    G2048_ERR_HIP = -2,    /* a HIP runtime call failed; see g2048_last_error */
+    G2048_ERR_NOMEM = -3,  /* device or host allocation failed */
+    G2048_ERR_STATE = -4,  /* call not valid in this state (e.g. no weight table: n_tuple == 0) */
+    G2048_ERR_NODEV = -5   /* no usable GPU */
+};
+
+/* lane flag bits (g2048_get_carry) */
+#define G2048_LANE_HAS_PREV 1u /* `state is not None` in QAgent.episode, r_learning.py:226,238 */
+#define G2048_LANE_DONE 2u     /* episode finished and auto-reset is off */
+
+typedef struct g2048_ctx g2048_ctx;
+
+typedef struct g2048_stats {
+    uint64_t episodes;       /* games finished                         (self.step, r_learning.py:251) */
+    uint64_t moves;          /* board-steps executed                   (Game.odometer summed)         */
+    uint64_t score_sum;      /* sum of final scores                    (av1000, r_learning.py:298)    */
+    uint64_t best_score;     /* best final score                       (top_score, r_learning.py:302) */
+    uint64_t max_tile[20];   /* histogram of the largest tile of finished games (reached[], :307-309) */
+    uint64_t overflow16;     /* lanes ended because a 15+15 merge left the reference's tile domain    */
+} g2048_stats;
+
+/* ---- library / geometry (host only) */
+int g2048_abi_version(void);
+const char* g2048_strerror(int status);
+int g2048_device_count(int* count);
+int g2048_num_feat(int n_tuple);                      /* QAgent.parameter_shape, r_learning.py:88 -> 24/52/17/21/33 */
+int64_t g2048_table_slots(int n_tuple);               /* total fp32 slots of the flat table, init_weights :136-149 */
+int g2048_feature_layout(int n_tuple, int64_t* offsets, int64_t* sizes); /* per-feature first slot / slot count */
+
+/* ---- lifecycle.  n_tuple in {0 (environment only), 2, 3, 4, 5, 6}.  Lanes are seeded from
+ * splitmix64(seed + lane0 + lane) and start as fresh games (Game.__init__, game_logic.py:55-66). */
+int g2048_create(int device, uint32_t batch, int n_tuple, uint64_t seed, uint64_t lane0, g2048_ctx** out);
+int g2048_destroy(g2048_ctx* ctx);
+const char* g2048_last_error(const g2048_ctx* ctx);
+int g2048_sync(g2048_ctx* ctx);
+int g2048_timer_start(g2048_ctx* ctx);                /* hipEventRecord on the context's stream */
+int g2048_timer_stop(g2048_ctx* ctx, float* ms);      /* second event + elapsed time, synchronises */
+
+/* ---- lane state I/O (Game.row / Game.score and the locals of QAgent.episode) */
+int g2048_set_boards(g2048_ctx* ctx, const uint8_t* boards /* [B][16] */);
+int g2048_get_boards(g2048_ctx* ctx, uint8_t* boards /* [B][16] */);
+int g2048_set_scores(g2048_ctx* ctx, const int32_t* scores /* [B] */);
+int g2048_get_scores(g2048_ctx* ctx, int32_t* scores /* [B] */);
+int g2048_set_rng(g2048_ctx* ctx, const uint64_t* state /* [B][2] */);
+int g2048_get_rng(g2048_ctx* ctx, uint64_t* state /* [B][2] */);
+int g2048_get_carry(g2048_ctx* ctx, uint8_t* prev /* [B][16] */, float* label /* [B] */, uint8_t* flags /* [B] */);
+int g2048_clear_carry(g2048_ctx* ctx);                /* state, old_label = None, 0 (r_learning.py:226); clears DONE */
+int g2048_reset(g2048_ctx* ctx);                      /* new game in every lane from the lane's own stream */
+int g2048_set_auto_reset(g2048_ctx* ctx, int on);     /* on (default): a finished lane starts a new game at once */
+
+/* ---- environment */
+/* Game.pre_move for all four directions (game_logic.py:136-142).  changed: bit d set iff direction d moves. */
+int g2048_move_all(g2048_ctx* ctx, uint8_t* after /* [B][4][16] */, int32_t* reward /* [B][4] */, uint8_t* changed /* [B] */);
+/* Game.make_move (game_logic.py:144-148) with a per-lane direction; moved[i] = 1 iff the board changed */
+int g2048_apply_moves(g2048_ctx* ctx, const uint8_t* dirs /* [B] */, uint8_t* moved /* [B], may be NULL */);
+/* Game.game_over / empty_count / adjacent_pair_count (game_logic.py:101-110); any output may be NULL */
+int g2048_terminal(g2048_ctx* ctx, uint8_t* over, uint8_t* n_empty, uint8_t* n_pairs);
+/* Game.new_tile (game_logic.py:112-121) from the lane streams; full boards are left alone (k = 255).
+ * The (r10, k) draws used are exported so the same game can be replayed into the reference. */
+int g2048_spawn(g2048_ctx* ctx, uint8_t* r10 /* [B] or NULL */, uint8_t* k /* [B] or NULL */);
+int g2048_spawn_injected(g2048_ctx* ctx, const uint8_t* r10 /* [B] */, const uint8_t* k /* [B] */);
+/* nsteps x {uniformly random valid direction, move, spawn, terminal check / auto-reset}: BASELINE config 2 */
+int g2048_step_random(g2048_ctx* ctx, uint32_t nsteps);
+
+/* ---- features / value (need n_tuple != 0) */
+int g2048_features(g2048_ctx* ctx, int32_t* out /* [B][F] */);            /* f_n, r_learning.py:17-69 (no offsets) */
+int g2048_weights_set(g2048_ctx* ctx, const float* w, int64_t count);     /* flat, weight_signature group order */
+int g2048_weights_get(g2048_ctx* ctx, float* w, int64_t count);
+int g2048_weights_init(g2048_ctx* ctx, uint64_t seed, float scale);       /* U[0, scale): init_weights :139-149 uses 0.01 */
+int g2048_evaluate(g2048_ctx* ctx, float* value /* [B] */);               /* QAgent.evaluate, r_learning.py:202-203 */
+/* greedy afterstate choice (r_learning.py:229-237, game_logic.py:150-161 at depth 0): first maximum over the
+ * directions that change the board; action 255 / value 0 when none does.  values4 ([B][4], may be NULL) gets
+ * V(afterstate d) or -inf. */
+int g2048_eval_select(g2048_ctx* ctx, float* value /* [B] */, uint8_t* action /* [B] */, float* values4);
+
+/* ---- learning */
+/* QAgent.update (r_learning.py:207-214) for `count` (state, dw) records: += dw at every feature slot of the
+ * 8 symmetric images (fp32 atomic adds). */
+int g2048_update(g2048_ctx* ctx, const uint8_t* states /* [count][16] */, const float* dw /* [count] */, int64_t count);
+/* nsteps synchronous board-steps of QAgent.episode (r_learning.py:228-249) for every live lane: all lanes
+ * choose with the same table, then every (state, dw) record of the step is added.  alpha is used as given. */
+int g2048_td_steps(g2048_ctx* ctx, float alpha, uint32_t nsteps);
+/* the same, with HIP events around each of the step's two kernels (synchronises every step): average
+ * milliseconds per launch of k_td_play and k_td_update, for the roofline line of bench.py */
+int g2048_td_steps_profiled(g2048_ctx* ctx, float alpha, uint32_t nsteps, float* ms_play, float* ms_update);
+int g2048_stats_get(g2048_ctx* ctx, g2048_stats* out);
+int g2048_stats_reset(g2048_ctx* ctx);
+
+/* ---- multi-GPU plumbing.  Episodes are sharded by lane0 (no data-path collective); once per epoch the host
+ * sum-all-reduces the fp32 weight delta with RCCL (torch.distributed backend "nccl") over xGMI:
+ *   delta_begin (W0 = W) ... E x td_steps ... delta_extract (D = W - W0) -> all_reduce(D) -> delta_apply (W = W0 + D).
+ * dst/src are DEVICE pointers to fp32[table_slots] owned by the caller (e.g. a torch tensor), or NULL to use
+ * the context's own buffer (g2048_delta_device_ptr).  Both calls synchronise the context's stream. */
+int g2048_weights_device_ptr(g2048_ctx* ctx, void** ptr, int64_t* count);
+int g2048_delta_begin(g2048_ctx* ctx);
+int g2048_delta_extract(g2048_ctx* ctx, void* dst);
+int g2048_delta_apply(g2048_ctx* ctx, const void* src);
+int g2048_delta_device_ptr(g2048_ctx* ctx, void** ptr);
+int g2048_stream_handle(g2048_ctx* ctx, void** hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* G2048_H */

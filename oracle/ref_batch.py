@@ -173,10 +173,13 @@ def d4_images(boards):
 # ------------------------------------------------------------------ value / select / update (a-9 .. a-12)
 
 def evaluate(n, weights, boards):
-    """QAgent.evaluate (r_learning.py:202-203): float64 left-to-right sum over features."""
+    """QAgent.evaluate (r_learning.py:202-203): left-to-right sum of one weight per feature.
+    Arithmetic follows the dtype of `weights`: float64 is the reference; float32 is the arithmetic model of the
+    device (same IEEE adds in the same order), used where a test wants bit-equal trajectories."""
     s = slots(n, boards)
-    w = np.asarray(weights, dtype=np.float64)
-    total = np.zeros(len(s), dtype=np.float64)
+    w = np.asarray(weights)
+    assert w.dtype in (np.float64, np.float32)
+    total = np.zeros(len(s), dtype=w.dtype)
     for i in range(s.shape[1]):
         total = total + w[s[:, i]]
     return total
@@ -201,7 +204,7 @@ def select(n, weights, boards):
 def update(n, weights, states, dw):
     """QAgent.update (r_learning.py:207-214) for a batch of (state, dw) records: weights[slot] += dw for
     every feature of the 8 symmetric images (coincident slots accumulate).  In place on float64 `weights`."""
-    dw = np.asarray(dw, dtype=np.float64)
+    dw = np.asarray(dw, dtype=weights.dtype)
     for img in d4_images(states):
         s = slots(n, img)
         np.add.at(weights, s.ravel(), np.repeat(dw, s.shape[1]))
@@ -224,22 +227,25 @@ class Lanes:
         self.moves = np.zeros(B, dtype=np.int64)
 
 
-def td_step(n, weights, lanes, alpha, draws, value_dtype=np.float64):
+def td_step(n, weights, lanes, alpha, draws):
     """One synchronous board-step for every live lane: the body of the while loop of QAgent.episode
     (r_learning.py:228-246) plus, for lanes whose game ends after the spawn, the terminal update
     (r_learning.py:247-249).  All lanes read the same `weights`; every (state, dw) record of the step is
     then applied with `update` (a sum, so lane order is irrelevant).  With one lane this is exactly the
-    reference's online TD.  `draws(lane_idx, n_empty) -> (r10, k)` supplies spawn draws.
+    reference's online TD.  `draws(lane_idx, n_empty) -> (r10, k)` supplies spawn draws.  Arithmetic follows
+    weights.dtype (float64 = reference, float32 = device model; see `evaluate`).
     Returns dict of per-lane arrays for inspection."""
-    F = rs.NUM_FEAT[n]
+    dt = weights.dtype.type
+    F = dt(rs.NUM_FEAT[n])
+    alpha = dt(alpha)
     live = ~lanes.done
     idx = np.nonzero(live)[0]
-    action, value, after, reward, any_valid, _ = select(n, weights, lanes.boards[idx])
+    action, value, after, reward, any_valid, vals = select(n, weights, lanes.boards[idx])
     assert any_valid.all(), 'a live lane must have a move'
-    value = value.astype(value_dtype).astype(np.float64)
+    value = value.astype(weights.dtype)               # (select keeps values in a float64 array)
     rec_states, rec_dw = [], []
     hp = lanes.has_prev[idx]
-    dw1 = (reward + value - lanes.label[idx]) * alpha / F          # r_learning.py:240
+    dw1 = (reward.astype(weights.dtype) + value - lanes.label[idx].astype(weights.dtype)) * alpha / F   # r_learning.py:240
     rec_states.append(lanes.prev[idx][hp])
     rec_dw.append(dw1[hp])
     # commit afterstate, r_learning.py:242-245
@@ -257,6 +263,7 @@ def td_step(n, weights, lanes, alpha, draws, value_dtype=np.float64):
     rec_states.append(after[over])
     rec_dw.append(dw2[over])
     lanes.done[idx[over]] = True
-    update(n, weights, np.concatenate(rec_states), np.concatenate(rec_dw))
-    return dict(lanes=idx, action=action, value=value, reward=reward, dw=np.where(hp, dw1, 0.0),
+    rec_states, rec_dw = np.concatenate(rec_states), np.concatenate(rec_dw)
+    update(n, weights, rec_states, rec_dw)
+    return dict(rec_states=rec_states, rec_dw=rec_dw, lanes=idx, action=action, value=value, values4=vals, reward=reward, dw=np.where(hp, dw1, 0.0),
                 over=over, dw_term=np.where(over, dw2, 0.0))

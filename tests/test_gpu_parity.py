@@ -1,0 +1,369 @@
+"""Parity of the HIP path (through the C ABI, include/g2048.h) against the oracle and the golden vectors.
+Integer work (moves, scores, spawns, terminal tests, tuple indices, RNG) must be bit-exact; fp32 values and
+weights must be within the tolerance of SURVEY.md §8 a-9: |V_gpu - V_ref| <= 1e-5 * sum|w_i| + 1e-6."""
+import importlib
+
+import numpy as np
+import pytest
+
+from oracle import ref_batch as rb
+from oracle import ref_scalar as rs
+from tests import helpers
+from tests.golden import formulas
+
+pytestmark = pytest.mark.gpu
+pkg = importlib.import_module('2048_amd')
+rng_spec = pkg.rng
+
+
+def Engine(*a, **k):
+    return pkg.Engine(*a, **k)
+
+
+def value_tol(n, weights, boards):
+    """1e-5 * sum |w_i| + 1e-6 per board."""
+    s = rb.slots(n, boards)
+    return 1e-5 * np.abs(np.asarray(weights, np.float64)[s]).sum(axis=1) + 1e-6
+
+
+# ------------------------------------------------------------------ environment: bit-exact
+
+def test_move_table_all_rows_all_directions(golden):
+    g = golden('move_table.npz')
+    keys = np.arange(65536)
+    line = np.stack([(keys >> 12) & 15, (keys >> 8) & 15, (keys >> 4) & 15, keys & 15], axis=1).astype(np.uint8)
+    eng = Engine(65536)
+    boards = np.zeros((65536, 4, 4), np.uint8)
+    boards[:, 2, :] = line
+    eng.set_boards(boards)
+    after, reward, changed = eng.move_all()
+    assert np.array_equal(after[:, 0, 2, :], g['out'])                       # left
+    assert np.array_equal(reward[:, 0], g['score'])
+    assert np.array_equal(changed & 1, g['changed'])
+    boards = np.zeros((65536, 4, 4), np.uint8)
+    boards[:, 1, ::-1] = line
+    eng.set_boards(boards)
+    after, reward, changed = eng.move_all()
+    assert np.array_equal(after[:, 2, 1, ::-1], g['out'])                    # right = left on the mirrored row
+    assert np.array_equal(reward[:, 2], g['score'])
+    boards = np.zeros((65536, 4, 4), np.uint8)
+    boards[:, :, 3] = line
+    eng.set_boards(boards)
+    after, reward, changed = eng.move_all()
+    assert np.array_equal(after[:, 1, :, 3], g['out'])                       # up
+    assert np.array_equal((changed >> 1) & 1, g['changed'])
+    boards = np.zeros((65536, 4, 4), np.uint8)
+    boards[:, ::-1, 0] = line
+    eng.set_boards(boards)
+    after, reward, changed = eng.move_all()
+    assert np.array_equal(after[:, 3, ::-1, 0], g['out'])                    # down
+    assert np.array_equal(reward[:, 3], g['score'])
+    eng.close()
+
+
+def test_golden_moves_terminal_spawn(golden):
+    g = golden('moves.npz')
+    B = len(g['boards'])                                                     # ragged: not a multiple of 64 or 256
+    eng = Engine(B)
+    eng.set_boards(g['boards'])
+    after, reward, changed = eng.move_all()
+    assert np.array_equal(after, g['after'])
+    assert np.array_equal(reward, g['reward'])
+    assert np.array_equal(np.stack([(changed >> d) & 1 for d in range(4)], axis=1), g['changed'])
+    over, ne, npairs = eng.terminal()
+    assert np.array_equal(over, g['game_over'].astype(bool))
+    assert np.array_equal(ne, g['empty_count'])
+    assert np.array_equal(npairs, g['adjacent_pair_count'])
+    # make_move: board and score
+    dirs = (np.arange(B) % 4).astype(np.uint8)
+    eng.set_scores(np.arange(B))
+    moved = eng.apply_moves(dirs)
+    ar = np.arange(B)
+    assert np.array_equal(eng.get_boards(), g['after'][ar, dirs])
+    assert np.array_equal(eng.get_scores(), ar + g['reward'][ar, dirs])
+    assert np.array_equal(moved, g['changed'][ar, dirs].astype(bool))
+    eng.close()
+    s = golden('spawn.npz')
+    eng = Engine(len(s['boards']))
+    eng.set_boards(s['boards'])
+    eng.spawn_injected(s['r10'], s['k'])
+    assert np.array_equal(eng.get_boards(), s['after'])
+    eng.close()
+
+
+def test_full_boards_do_not_spawn_and_rng_untouched():
+    full = np.tile(np.array([[1, 2, 1, 2], [2, 1, 2, 1], [1, 2, 1, 2], [2, 1, 2, 1]], np.uint8), (300, 1, 1))
+    eng = Engine(300, seed=9)
+    eng.set_boards(full)
+    st = eng.get_rng()
+    r10, k = eng.spawn()
+    assert np.array_equal(eng.get_boards(), full) and (k == 255).all() and np.array_equal(eng.get_rng(), st)
+    eng.close()
+
+
+def test_rng_stream_new_games_and_exported_draws():
+    B, seed, lane0 = 1000, 2048, 12345
+    eng = Engine(B, seed=seed, lane0=lane0)
+    state = rng_spec.seed_lanes(seed, lane0, B)
+    want = helpers.oracle_new_games(state, np.arange(B))                     # create() starts every lane as a new game
+    assert np.array_equal(eng.get_boards(), want)
+    assert np.array_equal(eng.get_rng(), state)
+    for _ in range(5):                                                       # spawn exports the (r10, k) it used
+        before = eng.get_boards()
+        r10, k = eng.spawn()
+        w10, wk = rng_spec.spawn_draw_np(rng_spec.next_u64_np(state), rb.empty_count(before))
+        assert np.array_equal(r10, w10) and np.array_equal(k, wk)
+        nb, _, _ = rb.spawn_injected(before, r10, k)                         # replay the draws into the oracle
+        assert np.array_equal(eng.get_boards(), nb)
+    assert np.array_equal(eng.get_rng(), state)
+    eng.reset()
+    want = helpers.oracle_new_games(state, np.arange(B))
+    assert np.array_equal(eng.get_boards(), want) and (eng.get_scores() == 0).all()
+    eng.close()
+
+
+@pytest.mark.parametrize('B,steps', [(65536, 40), (777, 400)])
+def test_step_random_config2(B, steps):
+    """BASELINE config 2: env step only, random valid direction — bit-exact boards, scores, RNG and stats."""
+    eng = Engine(B, seed=31)
+    boards, scores, state = eng.get_boards(), eng.get_scores().astype(np.int64), eng.get_rng()
+    eng.step_random(steps)
+    want = helpers.oracle_step_random(boards, scores, state, steps)
+    assert np.array_equal(eng.get_boards(), boards)
+    assert np.array_equal(eng.get_scores(), scores)
+    assert np.array_equal(eng.get_rng(), state)
+    st = eng.stats()
+    assert st['moves'] == want['moves'] and st['episodes'] == want['episodes']
+    assert st['score_sum'] == want['score_sum'] and st['best_score'] == want['best']
+    assert np.array_equal(np.array(st['max_tile']), want['hist'])
+    eng.close()
+
+
+def test_step_random_without_auto_reset_runs_every_game_to_the_end():
+    B = 512
+    eng = Engine(B, seed=5)
+    eng.set_auto_reset(False)
+    boards, scores, state = eng.get_boards(), eng.get_scores().astype(np.int64), eng.get_rng()
+    eng.step_random(3000)
+    want = helpers.oracle_step_random(boards, scores, state, 3000, auto_reset=False)
+    assert want['done'].all()
+    assert np.array_equal(eng.get_boards(), boards) and np.array_equal(eng.get_scores(), scores)
+    assert rb.game_over(eng.get_boards()).all()
+    assert eng.stats()['episodes'] == B
+    eng.close()
+
+
+# ------------------------------------------------------------------ features: bit-exact
+
+@pytest.mark.parametrize('n', [2, 3, 4, 5, 6])
+def test_features_golden(golden, n):
+    g = golden('features.npz')
+    eng = Engine(len(g['boards']), n=n)
+    eng.set_boards(g['boards'])
+    assert np.array_equal(eng.features(), g[f'f{n}'])
+    eng.close()
+
+
+# ------------------------------------------------------------------ value / select / update
+
+@pytest.mark.parametrize('n', [2, 3, 4, 5, 6])
+def test_value_select_update_golden(golden, n):
+    g = golden('learner.npz')
+    w = formulas.weights(n)
+    eng = Engine(len(g['boards']), n=n)
+    eng.set_weights(w)
+    eng.set_boards(g['boards'])
+    v = eng.evaluate()
+    assert np.array_equal(v.astype(np.float64), g[f'value{n}'])              # dyadic weights: exact in fp32 too
+    eng.close()
+    eng = Engine(len(g['sel_boards']), n=n)
+    eng.set_weights(w)
+    eng.set_boards(g['sel_boards'])
+    value, action, v4 = eng.eval_select(want_all=True)
+    assert np.array_equal(action, g[f'action{n}'])
+    o_action, o_value, _, _, _, o_vals = rb.select(n, w.astype(np.float64), g['sel_boards'])
+    assert np.array_equal(v4.astype(np.float64), o_vals) and np.array_equal(value.astype(np.float64), o_value)
+    # update: the reference's sparse table difference
+    eng.update(g['up_states'], g['up_dw'])
+    diff = eng.get_weights().astype(np.float64) - w.astype(np.float64)
+    nz = np.nonzero(diff)[0]
+    assert np.array_equal(nz, g[f'upd_slot{n}'])
+    assert np.allclose(diff[nz], g[f'upd_delta{n}'], rtol=0, atol=1e-6)
+    eng.close()
+
+
+def test_eval_select_config3_full_size():
+    """BASELINE config 3: 262 144 boards, n = 3, evaluate + 4-way greedy select, against the oracle."""
+    n, B = 3, 262144
+    eng = Engine(B, n=n, seed=77)
+    eng.step_random(48)                                                      # mid-game-like boards
+    w = np.random.RandomState(3).rand(formulas.table_size(n)).astype(np.float32) / 100   # U[0, 0.01) as init_weights
+    eng.set_weights(w)
+    boards = eng.get_boards()
+    value, action, v4 = eng.eval_select(want_all=True)
+    o_action, o_value, o_after, _, valid, o_vals = rb.select(n, w.astype(np.float64), boards)
+    assert valid.all()
+    fin = np.isfinite(o_vals)
+    assert np.array_equal(np.isfinite(v4), fin)
+    tol = 1e-5 * 52 * 0.01 + 1e-6
+    assert np.abs(v4[fin] - o_vals[fin]).max() <= tol
+    # the action may only differ where the oracle's two best values are closer than the tolerance
+    diff = np.nonzero(action != o_action)[0]
+    srt = np.sort(o_vals[diff], axis=1)
+    assert (srt[:, -1] - srt[:, -2] <= 2 * tol).all()
+    assert len(diff) < B // 1000
+    eng.close()
+
+
+@pytest.mark.parametrize('n', [2, 4, 5, 6])
+def test_update_linearity_full_size(n):
+    """Size-independent property at 2^20 records: every record adds dw to 8 * num_feat slots, so the table sum
+    moves by 8 * F * sum(dw); and update(+dw) followed by update(-dw) restores the table."""
+    B = 1 << 20 if n != 6 else 1 << 18
+    F = rs.NUM_FEAT[n]
+    eng = Engine(B, n=n, seed=4)
+    eng.step_random(32)
+    states = eng.get_boards()
+    dw = ((np.arange(B) % 17) - 8).astype(np.float32) * np.float32(2.0 ** -10)
+    eng.update(states, dw)
+    w = eng.get_weights()
+    assert abs(float(w.astype(np.float64).sum()) - 8 * F * float(dw.astype(np.float64).sum())) < 1e-3 * 8 * F
+    # against the oracle on a slice (float64)
+    sl = slice(0, 20000)
+    ref = np.zeros(formulas.table_size(n), np.float64)
+    rb.update(n, ref, states[sl], dw[sl].astype(np.float64))
+    eng2 = Engine(20000, n=n)
+    eng2.update(states[sl], dw[sl])
+    assert np.abs(eng2.get_weights().astype(np.float64) - ref).max() < 1e-4
+    eng2.close()
+    eng.update(states, -dw)
+    assert np.abs(eng.get_weights()).max() < 1e-3                            # dyadic dw: sums cancel up to fp32 order effects
+    eng.close()
+
+
+# ------------------------------------------------------------------ TD(0)
+
+@pytest.mark.parametrize('n', [2, 3, 4])
+def test_td_single_lane_reproduces_reference_episode(golden, n):
+    """Batch 1, same weights, same (r10, k) draws as the reference's QAgent.episode(): every board, action and
+    score of the whole game is identical; the learned table matches within fp32 tolerance."""
+    g = golden(f'episode_n{n}.npz')
+    eng = Engine(1, n=n, seed=int(g['seed']))
+    eng.set_auto_reset(False)
+    w0 = formulas.weights(n, scale=2.0 ** -6)
+    eng.set_weights(w0)
+    assert np.array_equal(eng.get_boards()[0], g['start'])                   # same two opening spawns
+    steps = len(g['moves']) - 1
+    for t in range(steps):
+        assert np.array_equal(eng.get_boards()[0], g['boards'][t]), f'board differs at move {t}'
+        assert eng.get_scores()[0] == g['scores'][t]
+        eng.td_steps(float(g['alpha']), 1)
+    assert np.array_equal(eng.get_boards()[0], g['final_board'])
+    assert eng.get_scores()[0] == int(g['final_score'])
+    _, _, flags = eng.get_carry()
+    assert flags[0] & 2                                                      # DONE
+    st = eng.stats()
+    assert st['episodes'] == 1 and st['moves'] == steps and st['score_sum'] == int(g['final_score'])
+    diff = eng.get_weights().astype(np.float64) - w0.astype(np.float64)
+    want = np.zeros_like(diff)
+    want[g['w_slot']] = g['w_delta']
+    assert np.abs(diff - want).max() < 5e-5      # fp32 table, |dw| up to ~10, up to 16 adds per slot
+    eng.td_steps(float(g['alpha']), 3)                                       # a finished lane stays put
+    assert np.array_equal(eng.get_boards()[0], g['final_board'])
+    eng.close()
+
+
+@pytest.mark.parametrize('n', [2, 3, 4, 5, 6])
+def test_td_steps_batch_vs_oracle(n):
+    """Synchronous batched TD(0), 4096 lanes: every step is checked against the float64 oracle started from the
+    device's own state (dyadic weights, so the comparison of boards, scores, RNG and labels is exact)."""
+    B = 4096
+    alpha = formulas.exact_alpha(n)
+    eng = Engine(B, n=n, seed=100 + n)
+    eng.set_auto_reset(False)
+    eng.step_random(30)                                                      # mid-game boards
+    for t in range(5):
+        helpers.check_td_step(eng, n, alpha, formulas.weights(n, scale=2.0 ** -(4 + t)))
+    eng.close()
+
+
+def test_td_batch_until_all_games_end():
+    """256 lanes played to the end with learning on: the per-step check holds through terminal updates and DONE."""
+    n, B = 2, 256
+    eng = Engine(B, n=n, seed=99)
+    eng.set_auto_reset(False)
+    w = formulas.weights(n, scale=2.0 ** -5)
+    ended = 0
+    for t in range(1500):
+        _, out = helpers.check_td_step(eng, n, formulas.exact_alpha(n), w)
+        ended += int(out['over'].sum())
+        if ended == B:
+            break
+    assert ended == B and eng.stats()['episodes'] == B
+    eng.close()
+
+
+def test_td_whole_game_fp32_model_bit_exact():
+    """One lane, one whole game with random (non-dyadic) weights, against the oracle run in the device's
+    arithmetic (float32, same operation order): boards and scores are bit-identical for the whole game, and so
+    is every weight (up to the order of the last step's two records on a shared slot)."""
+    n, alpha, seed = 2, 0.25, 321
+    eng = Engine(1, n=n, seed=seed)
+    eng.set_auto_reset(False)
+    w0 = (np.random.RandomState(1).rand(formulas.table_size(n)) / 100).astype(np.float32)
+    eng.set_weights(w0)
+    w = w0.copy()
+    lanes = rb.Lanes(eng.get_boards())
+    draws = helpers.SpecDraws(eng.get_rng())
+    steps = 0
+    while not lanes.done[0] and steps < 5000:
+        rb.td_step(n, w, lanes, alpha, draws)
+        steps += 1
+    assert lanes.done[0]
+    eng.td_steps(alpha, steps)
+    assert np.array_equal(eng.get_boards(), lanes.boards)
+    assert eng.get_scores()[0] == lanes.scores[0]
+    got = eng.get_weights()
+    differ = np.nonzero(got != w)[0]            # only slots shared by the last step's two records may differ (add order)
+    assert len(differ) <= 8 * 24
+    assert np.allclose(got, w, rtol=1e-6, atol=0)
+    eng.close()
+
+
+def test_td_auto_reset_and_stats_consistency():
+    """Full-size property: with auto-reset on, every lane makes one move per step; finished games are counted
+    and restarted; the table stays finite."""
+    n, B, steps = 4, 1 << 16, 600
+    eng = Engine(B, n=n, seed=8)
+    eng.init_weights(seed=1, scale=0.01)
+    eng.td_steps(0.25 * 17 / (8 * B), steps)                                  # batch rule: alpha * F / (8 * lanes)
+    st = eng.stats()
+    assert st['moves'] == B * steps
+    assert st['episodes'] > 0 and st['score_sum'] > 0 and st['best_score'] >= st['score_sum'] / st['episodes']
+    assert sum(st['max_tile']) == st['episodes']
+    boards = eng.get_boards()
+    assert not rb.game_over(boards).any()                                    # finished lanes were restarted at once
+    assert np.isfinite(eng.get_weights()).all()
+    eng.close()
+
+
+# ------------------------------------------------------------------ error behaviour
+
+def test_error_codes():
+    from ctypes import byref, c_void_p
+    lib = pkg.load_library()
+    ctx = c_void_p()
+    assert lib.g2048_create(0, 16, 7, 0, 0, byref(ctx)) == -1                # bad n-tuple
+    assert lib.g2048_create(0, 0, 2, 0, 0, byref(ctx)) == -1                 # empty batch
+    assert lib.g2048_create(99, 16, 2, 0, 0, byref(ctx)) == -1               # no such device
+    eng = Engine(16)                                                         # environment only
+    with pytest.raises(Exception) as e:
+        eng.features()
+    assert e.value.status == -4
+    eng.close()
+    eng = Engine(16, n=2)
+    assert eng.lib.g2048_weights_set(eng.ctx, None, 5) == -1                 # null buffer
+    five = np.zeros(5, np.float32)
+    assert eng.lib.g2048_weights_set(eng.ctx, five.ctypes.data, 5) == -1     # wrong count
+    assert b'count' in eng.lib.g2048_last_error(eng.ctx)
+    eng.close()

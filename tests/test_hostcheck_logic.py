@@ -1,0 +1,143 @@
+"""The kernels' integer logic (2048_amd/csrc/board_ops.hpp, features.hpp), compiled for the HOST by
+tests/hostcheck (test-only), against the golden vectors and the oracle.  CPU only — this is how the SWAR
+move, spawn, terminal test, RNG and the n-tuple/D4 index code are checked in a container without a GPU.
+The real parity tests (through the C-ABI, on the GPU) are in test_gpu_parity.py."""
+import ctypes
+import importlib
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import ref_batch as rb
+from tests.conftest import ROOT
+
+rng_spec = importlib.import_module('2048_amd.rng')
+HC_DIR = os.path.join(ROOT, 'tests', 'hostcheck')
+
+
+@pytest.fixture(scope='module')
+def hc():
+    so = os.path.join(HC_DIR, 'libhostcheck.so')
+    src = os.path.join(HC_DIR, 'hostcheck.cpp')
+    subprocess.check_call(['g++', '-O2', '-std=c++17', '-shared', '-fPIC', '-Wno-unknown-pragmas', '-o', so, src])
+    return ctypes.CDLL(so)
+
+
+def ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def hc_move_all(hc, boards):
+    boards = np.ascontiguousarray(boards.reshape(-1, 16), np.uint8)
+    n = len(boards)
+    after = np.zeros((n, 4, 4, 4), np.uint8)
+    reward = np.zeros((n, 4), np.int32)
+    changed = np.zeros(n, np.uint8)
+    hc.hc_move_all(ptr(boards), ctypes.c_int64(n), ptr(after), ptr(reward), ptr(changed))
+    return after, reward, changed
+
+
+def test_every_row_of_the_move_table(hc, golden):
+    """All 65 536 rows, in all four directions, against the reference's table."""
+    g = golden('move_table.npz')
+    keys = np.arange(65536)
+    line = np.stack([(keys >> 12) & 15, (keys >> 8) & 15, (keys >> 4) & 15, keys & 15], axis=1).astype(np.uint8)
+    boards = np.zeros((65536, 4, 4), np.uint8)
+    boards[:, 1, :] = line                                   # the line as row 1 (left / right) ...
+    after, reward, changed = hc_move_all(hc, boards)
+    assert np.array_equal(after[:, 0, 1, :], g['out'])
+    assert np.array_equal(reward[:, 0], g['score'] * g['changed'])
+    assert np.array_equal(changed & 1, g['changed'])
+    # right = left on the mirrored line
+    assert np.array_equal(after[:, 2, 1, ::-1][:, :], hc_move_all(hc, boards[:, :, ::-1])[0][:, 0, 1, :])
+    boards = np.zeros((65536, 4, 4), np.uint8)
+    boards[:, :, 2] = line                                   # ... and as column 2 (up / down)
+    after, reward, changed = hc_move_all(hc, boards)
+    assert np.array_equal(after[:, 1, :, 2], g['out'])
+    assert np.array_equal(reward[:, 1], g['score'] * g['changed'])
+    assert np.array_equal((changed >> 1) & 1, g['changed'])
+
+
+def test_moves_terminal_spawn_vs_golden(hc, golden):
+    g = golden('moves.npz')
+    after, reward, changed = hc_move_all(hc, g['boards'])
+    assert np.array_equal(after, g['after'])
+    assert np.array_equal(reward * g['changed'], g['reward'])    # reference adds score only for changed rows: same sum
+    assert np.array_equal(reward, g['reward'])
+    bits = np.stack([(changed >> d) & 1 for d in range(4)], axis=1)
+    assert np.array_equal(bits, g['changed'])
+    n = len(g['boards'])
+    b = np.ascontiguousarray(g['boards'].reshape(n, 16))
+    over, ne, npairs, top = (np.zeros(n, np.uint8) for _ in range(4))
+    hc.hc_terminal(ptr(b), ctypes.c_int64(n), ptr(over), ptr(ne), ptr(npairs), ptr(top))
+    assert np.array_equal(over, g['game_over'])
+    assert np.array_equal(ne, g['empty_count'])
+    assert np.array_equal(npairs, g['adjacent_pair_count'])
+    assert np.array_equal(top, b.max(axis=1))
+    s = golden('spawn.npz')
+    sb = np.ascontiguousarray(s['boards'].reshape(-1, 16)).copy()
+    hc.hc_spawn_injected(ptr(sb), ctypes.c_int64(len(sb)), ptr(np.ascontiguousarray(s['r10'])), ptr(np.ascontiguousarray(s['k'])))
+    assert np.array_equal(sb.reshape(-1, 4, 4), s['after'])
+
+
+def test_random_boards_vs_oracle(hc):
+    r = np.random.RandomState(5)
+    boards = (r.randint(0, 16, (20000, 4, 4)) * (r.rand(20000, 4, 4) < 0.7)).astype(np.uint8)
+    after, reward, changed = hc_move_all(hc, boards)
+    o_after, o_reward, o_changed = rb.move_all(boards)
+    assert np.array_equal(after, o_after)
+    assert np.array_equal(reward, o_reward)
+    assert np.array_equal(np.stack([(changed >> d) & 1 for d in range(4)], axis=1).astype(bool), o_changed)
+
+
+@pytest.mark.parametrize('n', [2, 3, 4, 5, 6])
+def test_feature_slots_of_all_images(hc, golden, n):
+    g = golden('features.npz')
+    boards = np.ascontiguousarray(g['boards'].reshape(-1, 16))
+    F = g[f'f{n}'].shape[1]
+    out = np.zeros((len(boards), 8, F), np.int32)
+    assert hc.hc_image_slots(n, ptr(boards), ctypes.c_int64(len(boards)), ptr(out)) == 0
+    from oracle import ref_scalar as rs
+    offs, total = rs.feature_offsets(n)
+    assert np.array_equal(out[:, 0, :] - offs[None, :], g[f'f{n}'])          # identity image == reference f_n
+    assert out.min() >= 0 and out.max() < total
+    # the 8 images are the 8 the reference's update visits (as a multiset of slot lists)
+    imgs = rb.d4_images(g['boards'])
+    want = np.stack([rb.slots(n, im) for im in imgs], axis=1)                # [B, 8, F]
+    a = np.sort(out.reshape(len(boards), -1), axis=1)
+    b = np.sort(want.reshape(len(boards), -1), axis=1)
+    assert np.array_equal(a, b)
+    # and image by image: ours are indexed g = transpose | mirror_lr << 1 | mirror_ud << 2
+    x = g['boards']
+    for gi in range(8):
+        img = x
+        if gi & 2:
+            img = img[:, :, ::-1]
+        if gi & 4:
+            img = img[:, ::-1, :]
+        if gi & 1:
+            img = np.transpose(img, (0, 2, 1))
+        assert np.array_equal(out[:, gi, :], rb.slots(n, img))
+
+
+def test_rng_stream_and_new_games(hc):
+    seed, lane0, count, nd = 2048, 1000, 64, 16
+    draws = np.zeros((count, nd), np.uint64)
+    state = np.zeros((count, 2), np.uint64)
+    hc.hc_rng_stream(ctypes.c_uint64(seed), ctypes.c_uint64(lane0), ctypes.c_int64(count), nd, ptr(draws), ptr(state))
+    st = rng_spec.seed_lanes(seed, lane0, count)
+    for j in range(nd):
+        assert np.array_equal(rng_spec.next_u64_np(st), draws[:, j])
+    assert np.array_equal(st, state)
+    lane = rng_spec.LaneRng(seed, lane0 + 5)
+    assert [lane.next() for _ in range(nd)] == [int(v) for v in draws[5]]
+    boards = np.zeros((count, 16), np.uint8)
+    hc.hc_new_games(ctypes.c_uint64(seed), ctypes.c_uint64(lane0), ctypes.c_int64(count), ptr(boards))
+    st = rng_spec.seed_lanes(seed, lane0, count)
+    want = np.zeros((count, 4, 4), np.uint8)
+    for _ in range(2):
+        r10, k = rng_spec.spawn_draw_np(rng_spec.next_u64_np(st), rb.empty_count(want))
+        want, _, _ = rb.spawn_injected(want, r10, k)
+    assert np.array_equal(boards.reshape(-1, 4, 4), want)
