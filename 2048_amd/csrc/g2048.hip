@@ -5,8 +5,9 @@
 //   boards  uint4[B]      16 B   log2 tiles, row-major (game_logic.py:62 narrowed to u8)
 //   scores  int32[B]       4 B   Game.score
 //   rng     u64[B][2]     16 B   xoroshiro128++ state (spec: 2048_amd/rng.py)
-//   prev    uint4[2][B]   16 B   `state` of QAgent.episode (r_learning.py:226,245), double-buffered so that the
-//                                step's two update records need no extra copy (see k_td_play)
+//   prev    uint4[2][B]   16 B   `state` of QAgent.episode (r_learning.py:226,245) in packed form (4 row + 4 column 16-bit
+//                                indices, features.hpp), double-buffered so that the step's two update records need no
+//                                extra copy (see k_td_play)
 //   label   float[B]       4 B   `old_label`
 //   flags   u8[B]                HAS_PREV / DONE
 //   weights float[slots]         flat n-tuple table, feature-major, weight_signature group order
@@ -18,6 +19,7 @@
 
 #include <new>
 #include <string>
+#include <vector>
 
 #include "../../include/g2048.h"
 #include "features.hpp"
@@ -44,6 +46,18 @@ __device__ __forceinline__ Rng ld_rng(const ulonglong2* p, size_t i) {
     return g;
 }
 __device__ __forceinline__ void st_rng(ulonglong2* p, size_t i, const Rng& g) { p[i] = make_ulonglong2(g.s0, g.s1); }
+
+// `state` records are kept in packed form (features.hpp): x = R0|R1<<16, y = R2|R3<<16, z = C0|C1<<16, w = C2|C3<<16
+__device__ __forceinline__ Packed ld_packed(const uint4* p, size_t i) {
+    uint4 v = p[i];
+    Packed q;
+    q.R[0] = v.x & 0xFFFFu; q.R[1] = v.x >> 16; q.R[2] = v.y & 0xFFFFu; q.R[3] = v.y >> 16;
+    q.C[0] = v.z & 0xFFFFu; q.C[1] = v.z >> 16; q.C[2] = v.w & 0xFFFFu; q.C[3] = v.w >> 16;
+    return q;
+}
+__device__ __forceinline__ void st_packed(uint4* p, size_t i, const Packed& q) {
+    p[i] = make_uint4(q.R[0] | (q.R[1] << 16), q.R[2] | (q.R[3] << 16), q.C[0] | (q.C[1] << 16), q.C[2] | (q.C[3] << 16));
+}
 
 struct Stats {   // device mirror of g2048_stats (all u64)
     unsigned long long episodes, moves, score_sum, best_score, max_tile[20], overflow16;
@@ -332,10 +346,10 @@ __global__ __launch_bounds__(WG) void k_eval_select(const uint4* boards, uint32_
 
 // QAgent.update (r_learning.py:207-214), one of the 8 images: += dw at every feature slot
 template <int N>
-__device__ __forceinline__ void scatter_image(float* w, const Board& state, uint32_t g, float dw) {
+__device__ __forceinline__ void scatter_image(float* w, const Packed& state, uint32_t g, float dw) {
     constexpr int F = Shape<N>::F;
     uint32_t s[F];
-    feature_slots<N>(d4_image(pack_board(state), g), s);
+    feature_slots<N>(d4_image(state, g), s);
 #pragma unroll
     for (int f = 0; f < F; ++f) __hip_atomic_fetch_add(&w[s[f]], dw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -346,7 +360,7 @@ __global__ __launch_bounds__(WG) void k_update_records(float* w, const uint4* st
     uint32_t t = blockIdx.x * WG + threadIdx.x;
     uint32_t rec = t >> 3;
     if (rec >= count) return;
-    scatter_image<N>(w, ld_board(states, rec), t & 7u, dw[rec]);
+    scatter_image<N>(w, pack_board(ld_board(states, rec)), t & 7u, dw[rec]);
 }
 
 // Step part 1 — the body of `while not game.game_over` in QAgent.episode (r_learning.py:228-246) for every live
@@ -382,7 +396,7 @@ __global__ __launch_bounds__(WG) void k_td_play(uint4* boards, int32_t* scores, 
                     r |= 1;
                 }
                 score += reward;
-                st_board(prev_nxt, i, after);
+                st_packed(prev_nxt, i, pack_board(after));
                 old_label = c.value;
                 fl |= HAS_PREV;
                 moved = true;
@@ -397,7 +411,7 @@ __global__ __launch_bounds__(WG) void k_td_play(uint4* boards, int32_t* scores, 
             } else {
                 // a dead board was loaded: the reference's loop would not run; only the terminal update remains
                 over = true;
-                st_board(prev_nxt, i, ld_board(prev_cur, i));
+                prev_nxt[i] = prev_cur[i];
                 if (fl & HAS_PREV) {
                     dw2[i] = -old_label * alpha / F;
                     r |= 2;
@@ -433,8 +447,112 @@ __global__ __launch_bounds__(WG) void k_td_update(float* w, const uint4* prev_cu
     uint32_t lane = t >> 3, g = t & 7u;
     if (lane >= B) return;
     uint8_t r = rec[lane];
-    if (r & 1) scatter_image<N>(w, ld_board(prev_cur, lane), g, dw1[lane]);
-    if (r & 2) scatter_image<N>(w, ld_board(prev_nxt, lane), g, dw2[lane]);
+    if (r & 1) scatter_image<N>(w, ld_packed(prev_cur, lane), g, dw1[lane]);
+    if (r & 2) scatter_image<N>(w, ld_packed(prev_nxt, lane), g, dw2[lane]);
+}
+
+
+// ------------------------------------------------------------------------------------------------ LDS-owner update
+// Random fp32 atomics to HBM-side memory run at ~21 G adds/s on MI355X and collapse under the skew of real boards
+// (a few hot slots: 7.8 G/s measured, tools/atomic_bench.hip); k_td_update spends 22 ms per step of 2^20 lanes on
+// them.  The chip has 256 x 160 KiB = 40 MiB of LDS, more than the whole n <= 5 table (21 MB): so instead a
+// workgroup OWNS a 128 KiB slice of the table in LDS, streams the step's (state, dw) records (20 B each, L2/MALL
+// resident), computes for each record and each of the 8 images only the slots of ITS feature(s), accumulates the
+// hits with LDS atomics, and finally adds the slice to the table in HBM with coalesced accesses.  With one
+// workgroup per slice the flush is a plain read-modify-write (no global atomics at all, and bitwise reproducible
+// up to the LDS add order); when the records are split over `nparts` workgroups the flush uses contiguous atomics.
+struct Slice {
+    uint32_t variant;       // which features this workgroup encodes (see OwnVariant)
+    uint32_t lo, size;      // table slots [lo, lo + size), size <= OWN_SLOTS
+    uint32_t part, nparts;  // records [B * part / nparts, B * (part + 1) / nparts)
+};
+
+constexpr int OWN_WG = 1024;
+constexpr uint32_t OWN_SLOTS = 32768;      // 128 KiB of the CU's 160 KiB LDS
+
+// variant v of table N covers features [F0, F0 + FC)
+template <int N> struct OwnVariants { static constexpr int COUNT = Shape<N>::F < 21 ? Shape<N>::F : 21; static constexpr int f0(int v) { return v; } static constexpr int fc(int) { return 1; } };
+template <> struct OwnVariants<2> { static constexpr int COUNT = 1; static constexpr int f0(int) { return 0; } static constexpr int fc(int) { return 24; } };
+template <> struct OwnVariants<3> { static constexpr int COUNT = 7; static constexpr int f0(int v) { return 8 * v; } static constexpr int fc(int v) { return v < 6 ? 8 : 4; } };
+
+template <int N, int F0, int FC>
+__device__ __forceinline__ void own_accum(const Packed& p, float dw, float* acc, uint32_t lo, uint32_t size) {
+    constexpr int F = Shape<N>::F;
+#pragma unroll
+    for (uint32_t g = 0; g < 8; ++g) {
+        uint32_t s[F];
+        feature_slots<N>(d4_image(p, g), s);         // g is a constant after unrolling; unused slots are dead code
+#pragma unroll
+        for (int f = F0; f < F0 + FC; ++f) {
+            uint32_t local = s[f] - lo;
+            if (local < size) atomicAdd(&acc[local], dw);
+        }
+    }
+}
+
+template <int N, int V>
+__device__ __forceinline__ void own_run(float* acc, const Slice& s, const uint4* pc, const uint4* pn, const float* dw1, const float* dw2,
+                                        const uint8_t* rec, uint32_t B) {
+    constexpr int F0 = OwnVariants<N>::f0(V), FC = OwnVariants<N>::fc(V);
+    const uint32_t begin = (uint32_t)((uint64_t)B * s.part / s.nparts), end = (uint32_t)((uint64_t)B * (s.part + 1) / s.nparts);
+    for (uint32_t r = begin + threadIdx.x; r < end; r += OWN_WG) {
+        const uint8_t f = rec[r];
+        if (f & 1) own_accum<N, F0, FC>(ld_packed(pc, r), dw1[r], acc, s.lo, s.size);
+        if (f & 2) own_accum<N, F0, FC>(ld_packed(pn, r), dw2[r], acc, s.lo, s.size);
+    }
+}
+
+template <int N, int V>
+__device__ __forceinline__ void own_dispatch(float* acc, const Slice& s, const uint4* pc, const uint4* pn, const float* dw1, const float* dw2,
+                                             const uint8_t* rec, uint32_t B) {
+    if constexpr (V < OwnVariants<N>::COUNT) {
+        if (s.variant == (uint32_t)V)
+            own_run<N, V>(acc, s, pc, pn, dw1, dw2, rec, B);
+        else
+            own_dispatch<N, V + 1>(acc, s, pc, pn, dw1, dw2, rec, B);
+    }
+}
+
+template <int N>
+__global__ __launch_bounds__(OWN_WG) void k_td_update_owner(float* w, const uint4* prev_cur, const uint4* prev_nxt, const float* dw1,
+                                                            const float* dw2, const uint8_t* rec, uint32_t B, const Slice* slices) {
+    __shared__ float acc[OWN_SLOTS];
+    const Slice s = slices[blockIdx.x];
+    for (uint32_t j = threadIdx.x; j < s.size; j += OWN_WG) acc[j] = 0.0f;
+    __syncthreads();
+    own_dispatch<N, 0>(acc, s, prev_cur, prev_nxt, dw1, dw2, rec, B);
+    __syncthreads();
+    if (s.nparts == 1) {
+        for (uint32_t j = threadIdx.x; j < s.size; j += OWN_WG) {
+            float v = acc[j];
+            if (v != 0.0f) w[s.lo + j] += v;            // this workgroup is the only writer of the slice
+        }
+    } else {
+        for (uint32_t j = threadIdx.x; j < s.size; j += OWN_WG) {
+            float v = acc[j];
+            if (v != 0.0f) __hip_atomic_fetch_add(&w[s.lo + j], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// n = 6: the twelve 14^6-slot tables (361 MB) do not fit in LDS; their 96 adds per record stay global atomics
+template <int N, int F0>
+__global__ __launch_bounds__(WG) void k_td_update_tail(float* w, const uint4* prev_cur, const uint4* prev_nxt, const float* dw1,
+                                                       const float* dw2, const uint8_t* rec, uint32_t B) {
+    constexpr int F = Shape<N>::F;
+    uint32_t t = blockIdx.x * WG + threadIdx.x;
+    uint32_t lane = t >> 3, g = t & 7u;
+    if (lane >= B) return;
+    uint8_t r = rec[lane];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        if (!(r & (1 << k))) continue;
+        uint32_t s[F];
+        feature_slots<N>(d4_image(ld_packed(k ? prev_nxt : prev_cur, lane), g), s);
+        const float dw = k ? dw2[lane] : dw1[lane];
+#pragma unroll
+        for (int f = F0; f < F; ++f) __hip_atomic_fetch_add(&w[s[f]], dw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // init_weights (r_learning.py:139-149): U[0, scale) per slot, counter-based so any rank can build the same table
@@ -487,6 +605,9 @@ struct g2048_ctx {
     uint8_t* rec = nullptr;
     float *w = nullptr, *w0 = nullptr, *delta = nullptr;
     Stats* stats = nullptr;
+    Slice* slices = nullptr;            // LDS-owner update plan (device copy)
+    uint32_t n_slices = 0;
+    int update_mode = 1;                // 1: LDS-owner update (default), 0: global fp32 atomics
     void* scratch = nullptr;
     size_t scratch_bytes = 0;
     std::string err;
@@ -576,6 +697,46 @@ int dalloc(g2048_ctx* c, T** p, size_t count) {
         default: return fail((c), G2048_ERR_STATE, "bad n_tuple");         \
     }
 
+// Build the LDS-owner plan: which workgroup owns which table slice and which share of the records.
+int build_slices(g2048_ctx* c) {
+    if (c->n == 0) return G2048_OK;
+    std::vector<Slice> v;
+    auto add = [&](uint32_t variant, uint32_t lo, uint32_t size, uint32_t nparts) {
+        for (uint32_t p = 0; p < nparts; ++p) v.push_back(Slice{variant, lo, size, p, nparts});
+    };
+    const uint32_t big = c->B >= (1u << 16) ? 1u : 0u;     // tiny batches: one part per slice is plenty
+    if (c->n == 2) {
+        add(0, 0, Shape<2>::SLOTS, big ? 512 : 8);
+    } else if (c->n == 3) {
+        for (uint32_t g = 0; g < 7; ++g) add(g, g * 8u * 4096u, (g < 6 ? 8u : 4u) * 4096u, big ? 36 : 1);
+    } else {
+        const int nf = c->F < 21 ? c->F : 21;
+        // partition counts chosen so that the plan is about one workgroup per CU (256 CUs, one 128 KiB slice each)
+        const uint32_t quad_parts = !big ? 1 : (c->n == 4 ? 7 : 2);
+        for (int f = 0; f < nf; ++f) {
+            const uint32_t off = feature_offset(c->n, f), sz = feature_size(c->n, f);
+            for (uint32_t lo = 0; lo < sz; lo += OWN_SLOTS) add((uint32_t)f, off + lo, OWN_SLOTS, f < 17 ? quad_parts : 1);
+        }
+    }
+    c->n_slices = (uint32_t)v.size();
+    if (int rc = dalloc(c, &c->slices, v.size())) return rc;
+    HIP_TRY(c, hipMemcpy(c->slices, v.data(), v.size() * sizeof(Slice), hipMemcpyHostToDevice));
+    return G2048_OK;
+}
+
+// Step part 2 on the context's stream, in the selected mode
+int launch_update(g2048_ctx* c, const uint4* pc, const uint4* pn) {
+    const uint32_t B = c->B;
+    if (c->update_mode == 1) {
+        BY_N(c, (k_td_update_owner<N><<<c->n_slices, OWN_WG, 0, c->stream>>>(c->w, pc, pn, c->dw1, c->dw2, c->rec, B, c->slices)));
+        if (c->n == 6)
+            k_td_update_tail<6, 21><<<grid_for((uint64_t)B * 8), WG, 0, c->stream>>>(c->w, pc, pn, c->dw1, c->dw2, c->rec, B);
+    } else {
+        BY_N(c, (k_td_update<N><<<grid_for((uint64_t)B * 8), WG, 0, c->stream>>>(c->w, pc, pn, c->dw1, c->dw2, c->rec, B)));
+    }
+    return G2048_OK;
+}
+
 int shape_of(int n, int* F, uint64_t* slots) {
     switch (n) {
         case 0: *F = 0; *slots = 0; return 0;
@@ -644,7 +805,7 @@ int g2048_destroy(g2048_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* bufs[] = {c->boards, c->scores, c->rng, c->prev[0], c->prev[1], c->label, c->flags, c->dw1, c->dw2,
-                    c->rec,    c->w,      c->w0,  c->delta,   c->stats,   c->scratch};
+                    c->rec,    c->w,      c->w0,  c->delta,   c->stats,   c->scratch, c->slices};
     for (void* p : bufs)
         if (p) (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -691,6 +852,7 @@ int g2048_create(int device, uint32_t batch, int n_tuple, uint64_t seed, uint64_
         (rc = dalloc(c, &c->stats, 1)))
         return bail(rc);
     if (slots && (rc = dalloc(c, &c->w, slots))) return bail(rc);
+    if ((rc = build_slices(c))) return bail(rc);
     if (hipMemsetAsync(c->stats, 0, sizeof(Stats), c->stream) != hipSuccess ||
         hipMemsetAsync(c->prev[0], 0, B * sizeof(uint4), c->stream) != hipSuccess ||
         hipMemsetAsync(c->prev[1], 0, B * sizeof(uint4), c->stream) != hipSuccess ||
@@ -750,7 +912,16 @@ int g2048_get_carry(g2048_ctx* c, uint8_t* prev, float* label, uint8_t* flags) {
     if (!c) return G2048_ERR_ARG;
     if (int rc = bind(c)) return rc;
     int rc = G2048_OK;
-    if (prev && (rc = d2h(c, prev, c->prev[c->cur], (size_t)c->B * 16))) return rc;
+    if (prev) {
+        if ((rc = d2h(c, prev, c->prev[c->cur], (size_t)c->B * 16))) return rc;
+        for (size_t i = 0; i < c->B; ++i) {           // packed rows -> 16 tile bytes (host-side format conversion only)
+            uint32_t v[4];
+            memcpy(v, prev + 16 * i, 16);
+            const uint32_t rows[4] = {v[0] & 0xFFFFu, v[0] >> 16, v[1] & 0xFFFFu, v[1] >> 16};
+            for (int r = 0; r < 4; ++r)
+                for (int col = 0; col < 4; ++col) prev[16 * i + 4 * r + col] = (uint8_t)((rows[r] >> (12 - 4 * col)) & 0xFu);
+        }
+    }
     if (label && (rc = d2h(c, label, c->label, (size_t)c->B * 4))) return rc;
     if (flags && (rc = d2h(c, flags, c->flags, (size_t)c->B))) return rc;
     return rc;
@@ -945,10 +1116,17 @@ int g2048_td_steps(g2048_ctx* c, float alpha, uint32_t nsteps) {
         uint4* pn = c->prev[c->cur ^ 1];
         BY_N(c, (k_td_play<N><<<grid_for(B), WG, 0, c->stream>>>(c->boards, c->scores, c->rng, pc, pn, c->label, c->flags, B, c->w, alpha,
                                                                  c->dw1, c->dw2, c->rec, c->auto_reset, c->stats)));
-        BY_N(c, (k_td_update<N><<<grid_for((uint64_t)B * 8), WG, 0, c->stream>>>(c->w, pc, pn, c->dw1, c->dw2, c->rec, B)));
+        if (int rc = launch_update(c, pc, pn)) return rc;
         c->cur ^= 1;
     }
     return launched(c, "k_td_play/k_td_update");
+}
+
+int g2048_set_update_mode(g2048_ctx* c, int mode) {
+    if (!c) return G2048_ERR_ARG;
+    NEED(c, mode == 0 || mode == 1, "update mode must be 0 (global atomics) or 1 (LDS-owner)");
+    c->update_mode = mode;
+    return G2048_OK;
 }
 
 int g2048_td_steps_profiled(g2048_ctx* c, float alpha, uint32_t nsteps, float* ms_play, float* ms_update) {
@@ -967,7 +1145,7 @@ int g2048_td_steps_profiled(g2048_ctx* c, float alpha, uint32_t nsteps, float* m
         BY_N(c, (k_td_play<N><<<grid_for(B), WG, 0, c->stream>>>(c->boards, c->scores, c->rng, pc, pn, c->label, c->flags, B, c->w, alpha,
                                                                  c->dw1, c->dw2, c->rec, c->auto_reset, c->stats)));
         (void)hipEventRecord(e[1], c->stream);
-        BY_N(c, (k_td_update<N><<<grid_for((uint64_t)B * 8), WG, 0, c->stream>>>(c->w, pc, pn, c->dw1, c->dw2, c->rec, B)));
+        rc = launch_update(c, pc, pn);
         (void)hipEventRecord(e[2], c->stream);
         c->cur ^= 1;
         float a = 0, b = 0;

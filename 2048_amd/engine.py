@@ -171,6 +171,10 @@ class Engine:
     def td_steps(self, alpha, nsteps=1):
         self._c(self.lib.g2048_td_steps(self.ctx, float(alpha), int(nsteps)))
 
+    def set_update_mode(self, mode):
+        """1 = LDS-owner update kernel (default), 0 = global fp32 atomics."""
+        self._c(self.lib.g2048_set_update_mode(self.ctx, int(mode)))
+
     def stats(self):
         st = _lib.Stats()
         self._c(self.lib.g2048_stats_get(self.ctx, ctypes.byref(st)))

@@ -111,6 +111,9 @@ int g2048_update(g2048_ctx* ctx, const uint8_t* states /* [count][16] */, const 
 /* nsteps synchronous board-steps of QAgent.episode (r_learning.py:228-249) for every live lane: all lanes
  * choose with the same table, then every (state, dw) record of the step is added.  alpha is used as given. */
 int g2048_td_steps(g2048_ctx* ctx, float alpha, uint32_t nsteps);
+/* how the step's records are added to the table: 1 (default) = LDS-owner kernel (workgroups own 128 KiB table
+ * slices in LDS, no global atomics for n <= 5), 0 = one global fp32 atomic per slot.  Same sums either way. */
+int g2048_set_update_mode(g2048_ctx* ctx, int mode);
 /* the same, with HIP events around each of the step's two kernels (synchronises every step): average
  * milliseconds per launch of k_td_play and k_td_update, for the roofline line of bench.py */
 int g2048_td_steps_profiled(g2048_ctx* ctx, float alpha, uint32_t nsteps, float* ms_play, float* ms_update);

@@ -5,7 +5,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 
-#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s failed: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+#define CHECK(x) do { hipError_t err_ = (x); if (err_ != hipSuccess) { printf("%s failed: %s\n", #x, hipGetErrorString(err_)); exit(1); } } while (0)
 
 __device__ __forceinline__ uint32_t hash32(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
@@ -47,7 +47,9 @@ void run(const char* name, float* table, size_t entries, float* sink) {
     const uint32_t threads = 1u << 23, per_thread = 21;
     hipEvent_t a, b;
     CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+    printf("[%s] table=%p entries=%zu sink=%p\n", name, (void*)table, entries, (void*)sink);
     k<MODE><<<threads / 256, 256>>>(table, (uint32_t)entries - 1, per_thread, sink);
+    CHECK(hipGetLastError());
     CHECK(hipDeviceSynchronize());
     CHECK(hipEventRecord(a));
     for (int r = 0; r < 3; ++r) k<MODE><<<threads / 256, 256>>>(table, (uint32_t)entries - 1, per_thread, sink);
@@ -58,10 +60,13 @@ void run(const char* name, float* table, size_t entries, float* sink) {
     printf("%-28s table %8.1f MB : %8.3f ms/launch  %8.2f Gop/s\n", name, entries * 4 / 1e6, ms / 3, ops / (ms * 1e-3) / 1e9);
 }
 
-int main() {
+int main(int argc, char** argv) {
+    setvbuf(stdout, NULL, _IONBF, 0);
+    int only_lds = argc > 1;
     float* sink; CHECK(hipMalloc(&sink, 4));
     size_t sizes[] = {1u << 13, 1u << 18, 1u << 20, 1u << 22, 1u << 23, 1u << 25, 1u << 27};   // 32 KB .. 512 MB
     for (size_t e : sizes) {
+        if (only_lds) break;
         float* table; CHECK(hipMalloc(&table, e * 4)); CHECK(hipMemset(table, 0, e * 4));
         run<0>("f32 atomic add (no return)", table, e, sink);
         run<6>("f32 atomic add, skewed", table, e, sink);
