@@ -15,8 +15,10 @@
 // gathers + fp32 atomic adds; what bounds them is the memory system, not the VALU.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <new>
 #include <string>
 #include <vector>
@@ -363,21 +365,40 @@ __global__ __launch_bounds__(WG) void k_update_records(float* w, const uint4* st
     scatter_image<N>(w, pack_board(ld_board(states, rec)), t & 7u, dw[rec]);
 }
 
+// The (state, dw) records one TD step produces — the arguments of the calls to QAgent.update in QAgent.episode:
+//   main record of lane i : state = prev[cur][i] (the previous afterstate), dw1[i] = (reward + V(after) - old_label) * alpha / F
+//                           (r_learning.py:240); dw1[i] == 0 means "no record" (first move of a game, finished lane);
+//   terminal records      : (this step's afterstate, -V(after) * alpha / F) for lanes whose game ended after the spawn
+//                           (r_learning.py:248) — rare, so they go to a compact queue (one atomic counter bump per wave).
+struct TdRecs {
+    const uint4* state1;    // prev[cur]
+    float* dw1;             // [B]
+    uint4* qstate;          // [B] queue of terminal-record states (packed)
+    float* qdw;             // [B]
+    uint32_t* qcount;       // length of this step's queue
+    uint32_t* qcount_next;  // next step's counter, zeroed by k_td_play
+};
+
+__device__ __forceinline__ void push_terminal(const TdRecs& r, const Packed& state, float dw) {
+    uint32_t slot = atomicAdd(r.qcount, 1u);        // the compiler folds the wave's increments into one atomic
+    st_packed(r.qstate, slot, state);
+    r.qdw[slot] = dw;
+}
+
 // Step part 1 — the body of `while not game.game_over` in QAgent.episode (r_learning.py:228-246) for every live
-// lane, all reading the same table; emits up to two (state, dw) records per lane:
-//   record 1 (bit 0 of rec): state = prev[cur][i]  (the previous afterstate), dw1 = (reward + V(after) - old_label) * alpha / F
-//   record 2 (bit 1 of rec): state = prev[nxt][i]  (this step's afterstate),  dw2 = -V(after) * alpha / F   if the game ended
-// (r_learning.py:240 and :248).  Because `prev` is double-buffered both states are already in memory.
+// lane, all reading the same table.  `prev` is double-buffered: prev_cur holds `state`, prev_nxt receives this
+// step's afterstate, so the main record needs no copy.
 template <int N>
-__global__ __launch_bounds__(WG) void k_td_play(uint4* boards, int32_t* scores, ulonglong2* rng, const uint4* prev_cur, uint4* prev_nxt,
-                                                float* label, uint8_t* flags, uint32_t B, const float* __restrict__ w, float alpha,
-                                                float* dw1, float* dw2, uint8_t* rec, int auto_reset, Stats* stats) {
+__global__ __launch_bounds__(WG) void k_td_play(uint4* boards, int32_t* scores, ulonglong2* rng, uint4* prev_nxt, float* label, uint8_t* flags,
+                                                uint32_t B, const float* __restrict__ w, float alpha, TdRecs recs, int auto_reset,
+                                                Stats* stats) {
     constexpr float F = (float)Shape<N>::F;
     uint32_t i = blockIdx.x * WG + threadIdx.x;
+    if (i == 0) *recs.qcount_next = 0;
     bool moved = false;
     if (i < B) {
         uint8_t fl = flags[i];
-        uint8_t r = 0;
+        float dw1 = 0.0f;
         if (!(fl & DONE)) {
             Board b = ld_board(boards, i);
             Rng g = ld_rng(rng, i);
@@ -386,36 +407,26 @@ __global__ __launch_bounds__(WG) void k_td_play(uint4* boards, int32_t* scores, 
             Moves4 mv = all_moves(b);
             Choice c = choose<N>(w, mv);
             bool over, overflow = false;
-            Board after;
             if (c.action >= 0) {
                 Moved ch = pick(mv, (uint32_t)c.action);
-                after = ch.after;
                 int32_t reward = (int32_t)merged_score(ch.ma, ch.mb);
-                if (fl & HAS_PREV) {
-                    dw1[i] = ((float)reward + c.value - old_label) * alpha / F;
-                    r |= 1;
-                }
+                if (fl & HAS_PREV) dw1 = ((float)reward + c.value - old_label) * alpha / F;
                 score += reward;
-                st_packed(prev_nxt, i, pack_board(after));
+                Packed after = pack_board(ch.after);
+                st_packed(prev_nxt, i, after);
                 old_label = c.value;
                 fl |= HAS_PREV;
                 moved = true;
-                b = after;
+                b = ch.after;
                 spawn(b, g);
                 overflow = max_tile(b) >= 16u;
                 over = game_over(b) || overflow;
-                if (over) {
-                    dw2[i] = -c.value * alpha / F;
-                    r |= 2;
-                }
+                if (over) push_terminal(recs, after, -c.value * alpha / F);
             } else {
                 // a dead board was loaded: the reference's loop would not run; only the terminal update remains
                 over = true;
-                prev_nxt[i] = prev_cur[i];
-                if (fl & HAS_PREV) {
-                    dw2[i] = -old_label * alpha / F;
-                    r |= 2;
-                }
+                prev_nxt[i] = recs.state1[i];
+                if (fl & HAS_PREV) push_terminal(recs, ld_packed(recs.state1, i), -old_label * alpha / F);
             }
             if (over) {
                 count_finished(stats, b, score, overflow);
@@ -434,23 +445,24 @@ __global__ __launch_bounds__(WG) void k_td_play(uint4* boards, int32_t* scores, 
             label[i] = old_label;
             flags[i] = fl;
         }
-        rec[i] = r;
+        recs.dw1[i] = dw1;
     }
     count_moves(stats, moved);
 }
 
-// Step part 2 — apply the step's records: QAgent.update for record 1 and record 2 of every lane.
+// Step part 2, global-atomics form — QAgent.update for every record: thread t adds image (t & 7) of record (t >> 3);
+// records B .. B + qcount - 1 are the terminal queue.
 template <int N>
-__global__ __launch_bounds__(WG) void k_td_update(float* w, const uint4* prev_cur, const uint4* prev_nxt, const float* dw1,
-                                                  const float* dw2, const uint8_t* rec, uint32_t B) {
+__global__ __launch_bounds__(WG) void k_td_update(float* w, TdRecs recs, uint32_t B) {
     uint32_t t = blockIdx.x * WG + threadIdx.x;
-    uint32_t lane = t >> 3, g = t & 7u;
-    if (lane >= B) return;
-    uint8_t r = rec[lane];
-    if (r & 1) scatter_image<N>(w, ld_packed(prev_cur, lane), g, dw1[lane]);
-    if (r & 2) scatter_image<N>(w, ld_packed(prev_nxt, lane), g, dw2[lane]);
+    uint32_t r = t >> 3, g = t & 7u;
+    if (r < B) {
+        float dw = recs.dw1[r];
+        if (dw != 0.0f) scatter_image<N>(w, ld_packed(recs.state1, r), g, dw);
+    } else if (r - B < *recs.qcount) {
+        scatter_image<N>(w, ld_packed(recs.qstate, r - B), g, recs.qdw[r - B]);
+    }
 }
-
 
 // ------------------------------------------------------------------------------------------------ LDS-owner update
 // Random fp32 atomics to HBM-side memory run at ~21 G adds/s on MI355X and collapse under the skew of real boards
@@ -459,24 +471,86 @@ __global__ __launch_bounds__(WG) void k_td_update(float* w, const uint4* prev_cu
 // workgroup OWNS a 128 KiB slice of the table in LDS, streams the step's (state, dw) records (20 B each, L2/MALL
 // resident), computes for each record and each of the 8 images only the slots of ITS feature(s), accumulates the
 // hits with LDS atomics, and finally adds the slice to the table in HBM with coalesced accesses.  With one
-// workgroup per slice the flush is a plain read-modify-write (no global atomics at all, and bitwise reproducible
-// up to the LDS add order); when the records are split over `nparts` workgroups the flush uses contiguous atomics.
+// workgroup per slice the flush is a plain read-modify-write (no global atomics at all); when the records are split
+// over `nparts` workgroups the flush uses contiguous atomics.
 struct Slice {
-    uint32_t variant;       // which features this workgroup encodes (see OwnVariant)
-    uint32_t lo, size;      // table slots [lo, lo + size), size <= OWN_SLOTS
-    uint32_t part, nparts;  // records [B * part / nparts, B * (part + 1) / nparts)
+    uint32_t variant;       // which feature(s) this workgroup encodes (see OwnVariants)
+    uint32_t tlo, size;     // table slots [tlo, tlo + size) of that feature are held in LDS, size <= OWN_SLOTS
+    uint32_t dlo;           // where the slice is added at flush time: index into the orbit table D (n >= 4) or into w (n = 2, 3)
+    uint32_t part, nparts;  // records [count * part / nparts, count * (part + 1) / nparts)
+    uint32_t chunk;         // hit counter of this slice (load statistics for the planner)
 };
+
+// Symmetry orbits (n >= 4).  QAgent.update adds dw at f_i(g.x) for all 8 images g (r_learning.py:207-214).  Features
+// that the dihedral group maps onto each other (the 4 outer lines; the 4 inner lines; corner / edge / centre squares;
+// the 4 crosses) therefore receive the SAME multiset of adds up to a fixed permutation of the index nibbles:
+//     f_i(x) = perm_i(f_rep(h_i . x))  for all x   =>   delta_table_i[perm_i(k)] = D_rep[k].
+// So the owner kernel accumulates one table D per orbit (6 orbits instead of 21 features: 3.5x fewer index
+// computations, LDS adds and record scans) and k_apply_orbits adds D into every member table through its permutation.
+constexpr int MAX_ORBITS = 8, MAX_MEMBERS = 4;
+struct OrbitInfo {
+    uint32_t base, size;                // D[base .. base + size)
+    uint32_t nmem;
+    uint32_t off[MAX_MEMBERS];          // first table slot of each member feature
+    uint32_t perm[MAX_MEMBERS];         // 3 bits per output nibble p: the input nibble it takes (out nibble p = in nibble src[p])
+    uint32_t nibbles;                   // 4 or 5
+};
+struct OrbitTable {
+    uint32_t count, total;
+    OrbitInfo o[MAX_ORBITS];
+};
+
+G2048_HD uint32_t permute_nibbles(uint32_t k, uint32_t perm, uint32_t nibbles) {
+    uint32_t out = 0;
+    for (uint32_t p = 0; p < nibbles; ++p) out |= ((k >> (4u * ((perm >> (3u * p)) & 7u))) & 15u) << (4u * p);
+    return out;
+}
 
 constexpr int OWN_WG = 1024;
 constexpr uint32_t OWN_SLOTS = 32768;      // 128 KiB of the CU's 160 KiB LDS
+template <int FC> struct OwnUnroll { static constexpr int U = FC == 1 ? 4 : 1; };   // records in flight per thread (loads issued together)
 
-// variant v of table N covers features [F0, F0 + FC)
+// variant v of table N covers features [f0(v), f0(v) + fc(v))
 template <int N> struct OwnVariants { static constexpr int COUNT = Shape<N>::F < 21 ? Shape<N>::F : 21; static constexpr int f0(int v) { return v; } static constexpr int fc(int) { return 1; } };
 template <> struct OwnVariants<2> { static constexpr int COUNT = 1; static constexpr int f0(int) { return 0; } static constexpr int fc(int) { return 24; } };
 template <> struct OwnVariants<3> { static constexpr int COUNT = 7; static constexpr int f0(int v) { return 8 * v; } static constexpr int fc(int v) { return v < 6 ? 8 : 4; } };
 
+__device__ __forceinline__ Packed unpack4(const uint4& v) {
+    Packed q;
+    q.R[0] = v.x & 0xFFFFu; q.R[1] = v.x >> 16; q.R[2] = v.y & 0xFFFFu; q.R[3] = v.y >> 16;
+    q.C[0] = v.z & 0xFFFFu; q.C[1] = v.z >> 16; q.C[2] = v.w & 0xFFFFu; q.C[3] = v.w >> 16;
+    return q;
+}
+
+// One LDS add per lane — but first fold lanes that target the SAME slot: the LDS serialises same-address atomics,
+// and young boards put most of a wave on one slot (an empty line is index 0 of its table).  Up to two rounds: take
+// the slot of the first pending lane; if at least 8 lanes share it, sum their dw across the wave and issue one add.
+// Must be called by all 64 lanes of the wave (`hit` false for lanes with nothing to add).
+__device__ __forceinline__ void lds_add_folded(float* acc, uint32_t local, float dw, bool hit) {
+    bool fold = true;
+#pragma unroll
+    for (int round = 0; round < 2; ++round) {
+        const unsigned long long pending = __ballot(hit);
+        if (fold && pending != 0) {                 // wave-uniform
+            const int first = __ffsll((long long)pending) - 1;
+            const uint32_t lead = (uint32_t)__builtin_amdgcn_readlane((int)local, first);
+            const bool same = hit && local == lead;
+            if (__popcll(__ballot(same)) >= 8) {
+                float v = same ? dw : 0.0f;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+                if ((int)(threadIdx.x & 63) == first) atomicAdd(&acc[lead], v);
+                hit = hit && !same;
+            } else {
+                fold = false;
+            }
+        }
+    }
+    if (hit) atomicAdd(&acc[local], dw);
+}
+
 template <int N, int F0, int FC>
-__device__ __forceinline__ void own_accum(const Packed& p, float dw, float* acc, uint32_t lo, uint32_t size) {
+__device__ __forceinline__ void own_accum(const Packed& p, float dw, bool valid, float* acc, const Slice& sl, uint32_t& nhit) {
     constexpr int F = Shape<N>::F;
 #pragma unroll
     for (uint32_t g = 0; g < 8; ++g) {
@@ -484,75 +558,123 @@ __device__ __forceinline__ void own_accum(const Packed& p, float dw, float* acc,
         feature_slots<N>(d4_image(p, g), s);         // g is a constant after unrolling; unused slots are dead code
 #pragma unroll
         for (int f = F0; f < F0 + FC; ++f) {
-            uint32_t local = s[f] - lo;
-            if (local < size) atomicAdd(&acc[local], dw);
+            const uint32_t local = s[f] - sl.tlo;
+            const bool hit = valid && local < sl.size;
+            lds_add_folded(acc, local, dw, hit);
+            nhit += hit ? 1u : 0u;
         }
     }
 }
 
 template <int N, int V>
-__device__ __forceinline__ void own_run(float* acc, const Slice& s, const uint4* pc, const uint4* pn, const float* dw1, const float* dw2,
-                                        const uint8_t* rec, uint32_t B) {
-    constexpr int F0 = OwnVariants<N>::f0(V), FC = OwnVariants<N>::fc(V);
-    const uint32_t begin = (uint32_t)((uint64_t)B * s.part / s.nparts), end = (uint32_t)((uint64_t)B * (s.part + 1) / s.nparts);
-    for (uint32_t r = begin + threadIdx.x; r < end; r += OWN_WG) {
-        const uint8_t f = rec[r];
-        if (f & 1) own_accum<N, F0, FC>(ld_packed(pc, r), dw1[r], acc, s.lo, s.size);
-        if (f & 2) own_accum<N, F0, FC>(ld_packed(pn, r), dw2[r], acc, s.lo, s.size);
+__device__ __forceinline__ void own_run(float* acc, const Slice& s, const TdRecs& recs, uint32_t B, uint32_t* hits) {
+    constexpr int F0 = OwnVariants<N>::f0(V), FC = OwnVariants<N>::fc(V), OWN_UNROLL = OwnUnroll<FC>::U;
+    uint32_t nhit = 0;
+    {   // main records: this part's share of the lanes, OWN_UNROLL records per thread in flight; the loop bounds are
+        // wave-uniform so that every lane reaches lds_add_folded
+        const uint32_t begin = (uint32_t)((uint64_t)B * s.part / s.nparts), end = (uint32_t)((uint64_t)B * (s.part + 1) / s.nparts);
+        for (uint32_t base0 = begin; base0 < end; base0 += OWN_WG * OWN_UNROLL) {
+            uint4 st[OWN_UNROLL];
+            float dw[OWN_UNROLL];
+#pragma unroll
+            for (int u = 0; u < OWN_UNROLL; ++u) {
+                const uint32_t r = base0 + threadIdx.x + (uint32_t)u * OWN_WG;
+                const bool ok = r < end;
+                const uint32_t rr = ok ? r : end - 1;
+                st[u] = recs.state1[rr];
+                dw[u] = ok ? recs.dw1[rr] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < OWN_UNROLL; ++u) own_accum<N, F0, FC>(unpack4(st[u]), dw[u], dw[u] != 0.0f, acc, s, nhit);
+        }
     }
+    {   // terminal queue
+        const uint32_t q = *recs.qcount;
+        const uint32_t begin = (uint32_t)((uint64_t)q * s.part / s.nparts), end = (uint32_t)((uint64_t)q * (s.part + 1) / s.nparts);
+        for (uint32_t base0 = begin; base0 < end; base0 += OWN_WG) {
+            const uint32_t r = base0 + threadIdx.x;
+            const bool ok = r < end;
+            const uint32_t rr = ok ? r : end - 1;
+            own_accum<N, F0, FC>(ld_packed(recs.qstate, rr), recs.qdw[rr], ok, acc, s, nhit);
+        }
+    }
+    // load statistics for the planner: one counter bump per wave
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) nhit += __shfl_down(nhit, off);
+    if ((threadIdx.x & 63) == 0 && nhit) atomicAdd(&hits[s.chunk], nhit);
 }
 
 template <int N, int V>
-__device__ __forceinline__ void own_dispatch(float* acc, const Slice& s, const uint4* pc, const uint4* pn, const float* dw1, const float* dw2,
-                                             const uint8_t* rec, uint32_t B) {
+__device__ __forceinline__ void own_dispatch(float* acc, const Slice& s, const TdRecs& recs, uint32_t B, uint32_t* hits) {
     if constexpr (V < OwnVariants<N>::COUNT) {
         if (s.variant == (uint32_t)V)
-            own_run<N, V>(acc, s, pc, pn, dw1, dw2, rec, B);
+            own_run<N, V>(acc, s, recs, B, hits);
         else
-            own_dispatch<N, V + 1>(acc, s, pc, pn, dw1, dw2, rec, B);
+            own_dispatch<N, V + 1>(acc, s, recs, B, hits);
     }
 }
 
+// `dst` is the orbit table D (n >= 4) or the weight table itself (n = 2, 3)
 template <int N>
-__global__ __launch_bounds__(OWN_WG) void k_td_update_owner(float* w, const uint4* prev_cur, const uint4* prev_nxt, const float* dw1,
-                                                            const float* dw2, const uint8_t* rec, uint32_t B, const Slice* slices) {
+__global__ __launch_bounds__(OWN_WG) void k_td_update_owner(float* dst, TdRecs recs, uint32_t B, const Slice* slices, uint32_t* hits) {
     __shared__ float acc[OWN_SLOTS];
     const Slice s = slices[blockIdx.x];
     for (uint32_t j = threadIdx.x; j < s.size; j += OWN_WG) acc[j] = 0.0f;
     __syncthreads();
-    own_dispatch<N, 0>(acc, s, prev_cur, prev_nxt, dw1, dw2, rec, B);
+    own_dispatch<N, 0>(acc, s, recs, B, hits);
     __syncthreads();
     if (s.nparts == 1) {
         for (uint32_t j = threadIdx.x; j < s.size; j += OWN_WG) {
             float v = acc[j];
-            if (v != 0.0f) w[s.lo + j] += v;            // this workgroup is the only writer of the slice
+            if (v != 0.0f) dst[s.dlo + j] += v;         // this workgroup is the only writer of the slice
         }
     } else {
         for (uint32_t j = threadIdx.x; j < s.size; j += OWN_WG) {
             float v = acc[j];
-            if (v != 0.0f) __hip_atomic_fetch_add(&w[s.lo + j], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (v != 0.0f) __hip_atomic_fetch_add(&dst[s.dlo + j], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
 
+// D -> every member table of its orbit (plain read-modify-write: for one member the permutation is a bijection, and
+// members are different features, so no two threads touch the same slot), then D is cleared for the next step.
+__global__ __launch_bounds__(WG) void k_apply_orbits(float* w, float* D, OrbitTable t) {
+    const uint32_t K = blockIdx.x * WG + threadIdx.x;
+    if (K >= t.total) return;
+    const float v = D[K];
+    if (v == 0.0f) return;
+    D[K] = 0.0f;
+    uint32_t o = 0;
+#pragma unroll
+    for (uint32_t j = 1; j < MAX_ORBITS; ++j)
+        if (j < t.count && K >= t.o[j].base) o = j;
+    const OrbitInfo& oi = t.o[o];
+    const uint32_t k = K - oi.base;
+    for (uint32_t m = 0; m < oi.nmem; ++m) w[oi.off[m] + permute_nibbles(k, oi.perm[m], oi.nibbles)] += v;
+}
+
 // n = 6: the twelve 14^6-slot tables (361 MB) do not fit in LDS; their 96 adds per record stay global atomics
 template <int N, int F0>
-__global__ __launch_bounds__(WG) void k_td_update_tail(float* w, const uint4* prev_cur, const uint4* prev_nxt, const float* dw1,
-                                                       const float* dw2, const uint8_t* rec, uint32_t B) {
+__global__ __launch_bounds__(WG) void k_td_update_tail(float* w, TdRecs recs, uint32_t B) {
     constexpr int F = Shape<N>::F;
     uint32_t t = blockIdx.x * WG + threadIdx.x;
-    uint32_t lane = t >> 3, g = t & 7u;
-    if (lane >= B) return;
-    uint8_t r = rec[lane];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        if (!(r & (1 << k))) continue;
-        uint32_t s[F];
-        feature_slots<N>(d4_image(ld_packed(k ? prev_nxt : prev_cur, lane), g), s);
-        const float dw = k ? dw2[lane] : dw1[lane];
-#pragma unroll
-        for (int f = F0; f < F; ++f) __hip_atomic_fetch_add(&w[s[f]], dw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t r = t >> 3, g = t & 7u;
+    Packed p;
+    float dw;
+    if (r < B) {
+        dw = recs.dw1[r];
+        if (dw == 0.0f) return;
+        p = ld_packed(recs.state1, r);
+    } else if (r - B < *recs.qcount) {
+        dw = recs.qdw[r - B];
+        p = ld_packed(recs.qstate, r - B);
+    } else {
+        return;
     }
+    uint32_t s[F];
+    feature_slots<N>(d4_image(p, g), s);
+#pragma unroll
+    for (int f = F0; f < F; ++f) __hip_atomic_fetch_add(&w[s[f]], dw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // init_weights (r_learning.py:139-149): U[0, scale) per slot, counter-based so any rank can build the same table
@@ -601,12 +723,21 @@ struct g2048_ctx {
     uint4* prev[2] = {nullptr, nullptr};
     float* label = nullptr;
     uint8_t* flags = nullptr;
-    float *dw1 = nullptr, *dw2 = nullptr;
-    uint8_t* rec = nullptr;
+    float* dw1 = nullptr;               // main record of every lane (0 = none)
+    uint4* qstate = nullptr;            // terminal-record queue
+    float* qdw = nullptr;
+    uint32_t* qcount = nullptr;         // [2]: this step's / next step's queue length
+    uint32_t step_parity = 0;
     float *w = nullptr, *w0 = nullptr, *delta = nullptr;
     Stats* stats = nullptr;
-    Slice* slices = nullptr;            // LDS-owner update plan (device copy)
+    Slice* slices = nullptr;            // LDS-owner update plan (device copy, capacity MAX_SLICES)
     uint32_t n_slices = 0;
+    uint32_t* hits = nullptr;           // adds per table chunk since the last re-plan (load statistics)
+    uint32_t n_chunks = 0;
+    uint32_t steps_since_plan = 0, replan_every = 8;
+    std::vector<double> load;           // smoothed adds per step per chunk
+    float* D = nullptr;                 // per-orbit delta tables (n >= 4)
+    OrbitTable orbits = {};
     int update_mode = 1;                // 1: LDS-owner update (default), 0: global fp32 atomics
     void* scratch = nullptr;
     size_t scratch_bytes = 0;
@@ -697,43 +828,215 @@ int dalloc(g2048_ctx* c, T** p, size_t count) {
         default: return fail((c), G2048_ERR_STATE, "bad n_tuple");         \
     }
 
-// Build the LDS-owner plan: which workgroup owns which table slice and which share of the records.
-int build_slices(g2048_ctx* c) {
-    if (c->n == 0) return G2048_OK;
-    std::vector<Slice> v;
-    auto add = [&](uint32_t variant, uint32_t lo, uint32_t size, uint32_t nparts) {
-        for (uint32_t p = 0; p < nparts; ++p) v.push_back(Slice{variant, lo, size, p, nparts});
-    };
-    const uint32_t big = c->B >= (1u << 16) ? 1u : 0u;     // tiny batches: one part per slice is plenty
-    if (c->n == 2) {
-        add(0, 0, Shape<2>::SLOTS, big ? 512 : 8);
-    } else if (c->n == 3) {
-        for (uint32_t g = 0; g < 7; ++g) add(g, g * 8u * 4096u, (g < 6 ? 8u : 4u) * 4096u, big ? 36 : 1);
-    } else {
-        const int nf = c->F < 21 ? c->F : 21;
-        // partition counts chosen so that the plan is about one workgroup per CU (256 CUs, one 128 KiB slice each)
-        const uint32_t quad_parts = !big ? 1 : (c->n == 4 ? 7 : 2);
-        for (int f = 0; f < nf; ++f) {
-            const uint32_t off = feature_offset(c->n, f), sz = feature_size(c->n, f);
-            for (uint32_t lo = 0; lo < sz; lo += OWN_SLOTS) add((uint32_t)f, off + lo, OWN_SLOTS, f < 17 ? quad_parts : 1);
+// ---- symmetry orbits, found by brute force at context creation (the index functions are host-callable): feature i
+// belongs to the orbit of an earlier feature r if some image g and some nibble permutation make
+// f_i(x) == perm(f_r(g.x)) on a set of random boards.
+template <int N>
+uint32_t host_feature_index(const Packed& p, int f) {
+    uint32_t s[Shape<N>::F];
+    feature_slots<N>(p, s);
+    return s[f] - feature_offset(N, f);
+}
+
+template <int N>
+int find_orbits(g2048_ctx* c) {
+    constexpr int NF = Shape<N>::F < 21 ? Shape<N>::F : 21;
+    std::vector<Packed> boards;
+    uint64_t x = 0x2048;
+    for (int t = 0; t < 24; ++t) {
+        Board b;
+        for (int r = 0; r < 4; ++r) {
+            uint64_t z = splitmix64(x);
+            b.r[r] = (uint32_t)(z & 0x0F0F0F0Fu);
+        }
+        boards.push_back(pack_board(b));
+    }
+    OrbitTable& T = c->orbits;
+    T.count = 0;
+    T.total = 0;
+    for (int i = 0; i < NF; ++i) {
+        const uint32_t nib = i < 17 ? 4u : 5u;
+        bool placed = false;
+        for (uint32_t o = 0; o < T.count && !placed; ++o) {
+            if (T.o[o].nibbles != nib) continue;
+            int rep = -1;       // the orbit's representative = its first member
+            for (int j = 0; j < NF; ++j)
+                if (feature_offset(N, j) == T.o[o].off[0]) rep = j;
+            std::vector<uint32_t> order(nib);
+            for (uint32_t q = 0; q < nib; ++q) order[q] = q;
+            do {
+                uint32_t perm = 0;
+                for (uint32_t q = 0; q < nib; ++q) perm |= order[q] << (3u * q);
+                for (uint32_t g = 0; g < 8 && !placed; ++g) {
+                    bool ok = true;
+                    for (const Packed& p : boards)
+                        if (host_feature_index<N>(p, i) != permute_nibbles(host_feature_index<N>(d4_image(p, g), rep), perm, nib)) {
+                            ok = false;
+                            break;
+                        }
+                    if (ok) {
+                        if (T.o[o].nmem >= MAX_MEMBERS) return fail(c, G2048_ERR_STATE, "orbit larger than expected");
+                        T.o[o].off[T.o[o].nmem] = feature_offset(N, i);
+                        T.o[o].perm[T.o[o].nmem] = perm;
+                        ++T.o[o].nmem;
+                        placed = true;
+                    }
+                }
+            } while (!placed && std::next_permutation(order.begin(), order.end()));
+        }
+        if (!placed) {
+            if (T.count >= MAX_ORBITS) return fail(c, G2048_ERR_STATE, "more orbits than expected");
+            OrbitInfo& oi = T.o[T.count++];
+            oi = OrbitInfo{};
+            oi.base = T.total;
+            oi.size = feature_size(N, i);
+            oi.nibbles = nib;
+            oi.nmem = 1;
+            oi.off[0] = feature_offset(N, i);
+            uint32_t ident = 0;
+            for (uint32_t q = 0; q < nib; ++q) ident |= q << (3u * q);
+            oi.perm[0] = ident;
+            T.total += oi.size;
         }
     }
-    c->n_slices = (uint32_t)v.size();
-    if (int rc = dalloc(c, &c->slices, v.size())) return rc;
-    HIP_TRY(c, hipMemcpy(c->slices, v.data(), v.size() * sizeof(Slice), hipMemcpyHostToDevice));
     return G2048_OK;
 }
 
-// Step part 2 on the context's stream, in the selected mode
-int launch_update(g2048_ctx* c, const uint4* pc, const uint4* pn) {
-    const uint32_t B = c->B;
-    if (c->update_mode == 1) {
-        BY_N(c, (k_td_update_owner<N><<<c->n_slices, OWN_WG, 0, c->stream>>>(c->w, pc, pn, c->dw1, c->dw2, c->rec, B, c->slices)));
-        if (c->n == 6)
-            k_td_update_tail<6, 21><<<grid_for((uint64_t)B * 8), WG, 0, c->stream>>>(c->w, pc, pn, c->dw1, c->dw2, c->rec, B);
-    } else {
-        BY_N(c, (k_td_update<N><<<grid_for((uint64_t)B * 8), WG, 0, c->stream>>>(c->w, pc, pn, c->dw1, c->dw2, c->rec, B)));
+// ---- LDS-owner plan.  The accumulation space (orbit tables D for n >= 4, the weight table itself for n = 2, 3) is cut
+// into chunks of at most OWN_SLOTS slots.  Every chunk is held in LDS by `nparts` workgroups, each scanning a share of
+// the records; the ~250 workgroups (one 128 KiB workgroup per CU) are handed out in proportion to each chunk's cost =
+// scanning the records + its measured adds per step (hit counters, read back every `replan_every` steps): young
+// boards put almost every add into the low half of each table, a trained agent's boards do not.
+constexpr uint32_t MAX_SLICES = 1024;
+constexpr uint32_t WG_BUDGET = 250;
+
+struct ChunkInfo {
+    uint32_t variant, tlo, size, dlo;
+    double scan;        // relative cost of scanning one record for this chunk
+};
+
+std::vector<ChunkInfo> table_chunks(const g2048_ctx* c) {
+    std::vector<ChunkInfo> v;
+    if (c->n == 2) {
+        v.push_back({0, 0, Shape<2>::SLOTS, 0, 6.0});
+    } else if (c->n == 3) {
+        for (uint32_t g = 0; g < 7; ++g) v.push_back({g, g * 8u * 4096u, (g < 6 ? 8u : 4u) * 4096u, g * 8u * 4096u, 3.0});
+    } else if (c->n >= 4) {
+        for (uint32_t o = 0; o < c->orbits.count; ++o) {
+            const OrbitInfo& oi = c->orbits.o[o];
+            uint32_t rep = 0;
+            for (int j = 0; j < 21 && j < c->F; ++j)
+                if (feature_offset(c->n, j) == oi.off[0]) rep = (uint32_t)j;
+            for (uint32_t lo = 0; lo < oi.size; lo += OWN_SLOTS) v.push_back({rep, oi.off[0] + lo, OWN_SLOTS, oi.base + lo, oi.nibbles == 4 ? 1.0 : 2.0});
+        }
     }
+    return v;
+}
+
+int build_slices(g2048_ctx* c) {
+    if (c->n == 0) return G2048_OK;
+    if (!c->slices) {       // first call: orbits, device buffers, and a prior for the load
+        if (c->n >= 4) {
+            int rc = c->n == 4 ? find_orbits<4>(c) : c->n == 5 ? find_orbits<5>(c) : find_orbits<6>(c);
+            if (rc) return rc;
+            if ((rc = dalloc(c, &c->D, c->orbits.total))) return rc;
+            HIP_TRY(c, hipMemset(c->D, 0, (size_t)c->orbits.total * 4));
+        }
+        if (int rc = dalloc(c, &c->slices, MAX_SLICES)) return rc;
+    }
+    const std::vector<ChunkInfo> chunks = table_chunks(c);
+    const size_t nc = chunks.size();
+    if (!c->hits && getenv("G2048_DEBUG_PLAN"))
+        for (uint32_t o = 0; o < c->orbits.count; ++o) {
+            const OrbitInfo& oi = c->orbits.o[o];
+            fprintf(stderr, "[g2048 orbit %u] base %u size %u members:", o, oi.base, oi.size);
+            for (uint32_t m = 0; m < oi.nmem; ++m) fprintf(stderr, " (slot %u perm %05o)", oi.off[m], oi.perm[m]);
+            fprintf(stderr, "\n");
+        }
+    if (!c->hits) {
+        if (int rc = dalloc(c, &c->hits, nc)) return rc;
+        HIP_TRY(c, hipMemset(c->hits, 0, nc * 4));
+        c->n_chunks = (uint32_t)nc;
+        c->load.assign(nc, 0.0);
+        for (size_t k = 0; k < nc; ++k) {       // fresh games only touch small tiles: the low chunk of every table
+            double share = 1.0;
+            if (c->n >= 4) {
+                const uint32_t rel = (chunks[k].dlo % (chunks[k].scan == 1.0 ? 65536u : 1048576u)) / OWN_SLOTS;
+                share = chunks[k].scan == 1.0 ? (rel == 0 ? 0.99 : 0.01) : ((rel & 1) == 0 && rel < 16 ? 0.12 : 0.001);
+            }
+            c->load[k] = 8.0 * c->B * share * (c->n == 2 ? 24 : c->n == 3 ? (chunks[k].size / 4096.0) : 1);
+        }
+    }
+    double add_cost = 1.5;
+    if (const char* e = getenv("G2048_PLAN_ADDCOST")) add_cost = atof(e);      // (experiments)
+    const double B = c->B;
+    std::vector<double> cost(nc);
+    double total = 0;
+    for (size_t k = 0; k < nc; ++k) {
+        cost[k] = chunks[k].scan * B + add_cost * c->load[k];
+        total += cost[k];
+    }
+    const uint32_t budget = c->B < (1u << 14) ? (uint32_t)nc : (WG_BUDGET > nc ? WG_BUDGET : (uint32_t)nc);
+    std::vector<Slice> v;
+    std::vector<uint32_t> parts(nc);
+    for (size_t k = 0; k < nc; ++k) {
+        parts[k] = 1 + (uint32_t)((budget - nc) * cost[k] / total);
+        for (uint32_t p = 0; p < parts[k]; ++p) v.push_back(Slice{chunks[k].variant, chunks[k].tlo, chunks[k].size, chunks[k].dlo, p, parts[k], (uint32_t)k});
+    }
+    if (v.size() > MAX_SLICES) return fail(c, G2048_ERR_STATE, "LDS-owner plan too large");
+    // longest-running workgroups first
+    std::stable_sort(v.begin(), v.end(), [&](const Slice& a, const Slice& b) { return cost[a.chunk] / a.nparts > cost[b.chunk] / b.nparts; });
+    c->n_slices = (uint32_t)v.size();
+    if (getenv("G2048_DEBUG_PLAN")) {
+        fprintf(stderr, "[g2048 plan] %zu workgroups over %zu chunks; (chunk:load/parts)", v.size(), nc);
+        for (size_t k = 0; k < nc; ++k) fprintf(stderr, " %zu:%.3f/%u", k, c->load[k] / (8.0 * B), parts[k]);
+        fprintf(stderr, "\n");
+    }
+    HIP_TRY(c, hipMemcpyAsync(c->slices, v.data(), v.size() * sizeof(Slice), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->steps_since_plan = 0;
+    return G2048_OK;
+}
+
+// read the hit counters, fold them into the smoothed load and rebuild the plan (a few tens of microseconds)
+int replan(g2048_ctx* c) {
+    if (c->n < 4 || c->n_chunks == 0 || c->steps_since_plan == 0) return G2048_OK;
+    std::vector<uint32_t> h(c->n_chunks);
+    if (int rc = d2h(c, h.data(), c->hits, h.size() * 4)) return rc;
+    HIP_TRY(c, hipMemsetAsync(c->hits, 0, h.size() * 4, c->stream));
+    for (size_t k = 0; k < h.size(); ++k) c->load[k] = 0.5 * c->load[k] + 0.5 * (double)h[k] / c->steps_since_plan;
+    c->replan_every = c->replan_every < 64 ? c->replan_every * 2 : 64;
+    return build_slices(c);
+}
+
+// One TD step on the context's stream: k_td_play, then the update in the selected mode.  `ev` (optional) gets an
+// event between the two parts.
+int launch_td_step(g2048_ctx* c, float alpha, hipEvent_t ev = nullptr) {
+    const uint32_t B = c->B;
+    uint4* pn = c->prev[c->cur ^ 1];
+    TdRecs recs;
+    recs.state1 = c->prev[c->cur];
+    recs.dw1 = c->dw1;
+    recs.qstate = c->qstate;
+    recs.qdw = c->qdw;
+    recs.qcount = c->qcount + c->step_parity;
+    recs.qcount_next = c->qcount + (c->step_parity ^ 1u);
+    BY_N(c, (k_td_play<N><<<grid_for(B), WG, 0, c->stream>>>(c->boards, c->scores, c->rng, pn, c->label, c->flags, B, c->w, alpha, recs,
+                                                             c->auto_reset, c->stats)));
+    if (ev) (void)hipEventRecord(ev, c->stream);
+    if (c->update_mode == 1) {
+        if (c->steps_since_plan >= c->replan_every)
+            if (int rc = replan(c)) return rc;
+        ++c->steps_since_plan;
+        float* dst = c->n >= 4 ? c->D : c->w;
+        BY_N(c, (k_td_update_owner<N><<<c->n_slices, OWN_WG, 0, c->stream>>>(dst, recs, B, c->slices, c->hits)));
+        if (c->n >= 4) k_apply_orbits<<<grid_for(c->orbits.total), WG, 0, c->stream>>>(c->w, c->D, c->orbits);
+        if (c->n == 6) k_td_update_tail<6, 21><<<grid_for((uint64_t)B * 16), WG, 0, c->stream>>>(c->w, recs, B);
+    } else {
+        BY_N(c, (k_td_update<N><<<grid_for((uint64_t)B * 16), WG, 0, c->stream>>>(c->w, recs, B)));
+    }
+    c->cur ^= 1;
+    c->step_parity ^= 1u;
     return G2048_OK;
 }
 
@@ -804,8 +1107,8 @@ int g2048_destroy(g2048_ctx* c) {
     if (!c) return G2048_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void* bufs[] = {c->boards, c->scores, c->rng, c->prev[0], c->prev[1], c->label, c->flags, c->dw1, c->dw2,
-                    c->rec,    c->w,      c->w0,  c->delta,   c->stats,   c->scratch, c->slices};
+    void* bufs[] = {c->boards, c->scores, c->rng, c->prev[0], c->prev[1], c->label, c->flags, c->dw1, c->qstate,
+                    c->qdw,    c->qcount, c->w,      c->w0,  c->delta,   c->stats,   c->scratch, c->slices, c->hits, c->D};
     for (void* p : bufs)
         if (p) (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -848,7 +1151,8 @@ int g2048_create(int device, uint32_t batch, int n_tuple, uint64_t seed, uint64_
     const size_t B = batch;
     if ((rc = dalloc(c, &c->boards, B)) || (rc = dalloc(c, &c->scores, B)) || (rc = dalloc(c, &c->rng, B)) ||
         (rc = dalloc(c, &c->prev[0], B)) || (rc = dalloc(c, &c->prev[1], B)) || (rc = dalloc(c, &c->label, B)) ||
-        (rc = dalloc(c, &c->flags, B)) || (rc = dalloc(c, &c->dw1, B)) || (rc = dalloc(c, &c->dw2, B)) || (rc = dalloc(c, &c->rec, B)) ||
+        (rc = dalloc(c, &c->flags, B)) || (rc = dalloc(c, &c->dw1, B)) || (rc = dalloc(c, &c->qstate, B)) || (rc = dalloc(c, &c->qdw, B)) ||
+        (rc = dalloc(c, &c->qcount, 2)) ||
         (rc = dalloc(c, &c->stats, 1)))
         return bail(rc);
     if (slots && (rc = dalloc(c, &c->w, slots))) return bail(rc);
@@ -856,7 +1160,7 @@ int g2048_create(int device, uint32_t batch, int n_tuple, uint64_t seed, uint64_
     if (hipMemsetAsync(c->stats, 0, sizeof(Stats), c->stream) != hipSuccess ||
         hipMemsetAsync(c->prev[0], 0, B * sizeof(uint4), c->stream) != hipSuccess ||
         hipMemsetAsync(c->prev[1], 0, B * sizeof(uint4), c->stream) != hipSuccess ||
-        hipMemsetAsync(c->rec, 0, B, c->stream) != hipSuccess ||
+        hipMemsetAsync(c->qcount, 0, 8, c->stream) != hipSuccess || hipMemsetAsync(c->dw1, 0, B * 4, c->stream) != hipSuccess ||
         (slots && hipMemsetAsync(c->w, 0, slots * sizeof(float), c->stream) != hipSuccess))
         return bail(G2048_ERR_HIP);
     k_seed<<<grid_for(B), WG, 0, c->stream>>>(c->rng, batch, seed, lane0);
@@ -932,7 +1236,7 @@ int g2048_clear_carry(g2048_ctx* c) {
     if (int rc = bind(c)) return rc;
     HIP_TRY(c, hipMemsetAsync(c->flags, 0, c->B, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->label, 0, (size_t)c->B * 4, c->stream));
-    HIP_TRY(c, hipMemsetAsync(c->rec, 0, c->B, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->dw1, 0, (size_t)c->B * 4, c->stream));
     return G2048_OK;
 }
 
@@ -1110,15 +1414,8 @@ int g2048_td_steps(g2048_ctx* c, float alpha, uint32_t nsteps) {
     if (!c) return G2048_ERR_ARG;
     NEED_TABLE(c);
     if (int rc = bind(c)) return rc;
-    const uint32_t B = c->B;
-    for (uint32_t s = 0; s < nsteps; ++s) {
-        uint4* pc = c->prev[c->cur];
-        uint4* pn = c->prev[c->cur ^ 1];
-        BY_N(c, (k_td_play<N><<<grid_for(B), WG, 0, c->stream>>>(c->boards, c->scores, c->rng, pc, pn, c->label, c->flags, B, c->w, alpha,
-                                                                 c->dw1, c->dw2, c->rec, c->auto_reset, c->stats)));
-        if (int rc = launch_update(c, pc, pn)) return rc;
-        c->cur ^= 1;
-    }
+    for (uint32_t s = 0; s < nsteps; ++s)
+        if (int rc = launch_td_step(c, alpha)) return rc;
     return launched(c, "k_td_play/k_td_update");
 }
 
@@ -1133,21 +1430,14 @@ int g2048_td_steps_profiled(g2048_ctx* c, float alpha, uint32_t nsteps, float* m
     if (!c || !ms_play || !ms_update) return c ? fail(c, G2048_ERR_ARG, "null buffer") : G2048_ERR_ARG;
     NEED_TABLE(c);
     if (int rc = bind(c)) return rc;
-    const uint32_t B = c->B;
     hipEvent_t e[3];
     for (auto& ev : e) HIP_TRY(c, hipEventCreate(&ev));
     double tp = 0, tu = 0;
     int rc = G2048_OK;
     for (uint32_t s = 0; s < nsteps && rc == G2048_OK; ++s) {
-        uint4* pc = c->prev[c->cur];
-        uint4* pn = c->prev[c->cur ^ 1];
         (void)hipEventRecord(e[0], c->stream);
-        BY_N(c, (k_td_play<N><<<grid_for(B), WG, 0, c->stream>>>(c->boards, c->scores, c->rng, pc, pn, c->label, c->flags, B, c->w, alpha,
-                                                                 c->dw1, c->dw2, c->rec, c->auto_reset, c->stats)));
-        (void)hipEventRecord(e[1], c->stream);
-        rc = launch_update(c, pc, pn);
+        rc = launch_td_step(c, alpha, e[1]);
         (void)hipEventRecord(e[2], c->stream);
-        c->cur ^= 1;
         float a = 0, b = 0;
         if (hipEventSynchronize(e[2]) != hipSuccess || hipEventElapsedTime(&a, e[0], e[1]) != hipSuccess ||
             hipEventElapsedTime(&b, e[1], e[2]) != hipSuccess)

@@ -336,7 +336,7 @@ def test_td_whole_game_fp32_model_bit_exact(mode):
         differ = np.nonzero(got != w)[0]        # records may differ (their add order is free)
         assert len(differ) <= 8 * 24
     # mode 1 sums a step's adds to a slot in LDS first and adds the sum once: same value up to fp32 rounding
-    assert np.allclose(got, w, rtol=2e-6, atol=1e-9)
+    assert np.abs(got.astype(np.float64) - w).max() <= 1e-5 * max(1.0, float(np.abs(w).max()))
     eng.close()
 
 
@@ -352,15 +352,18 @@ def test_update_modes_agree_at_scale(n):
         eng.set_update_mode(mode)
         eng.step_random(40)
         eng.set_weights(formulas.weights(n, scale=2.0 ** -4))
-        eng.td_steps(2.0 ** -12, 2)                                          # step 1 has no `state` yet; step 2 updates
+        eng.td_steps(0.0, 1)                                                 # step 1 only sets `state` (alpha 0: no records)
+        eng.td_steps(2.0 ** -12, 1)                                          # step 2: same choices in both modes, then the adds
         tables.append((eng.get_weights().astype(np.float64), eng.get_boards(), eng.stats()['moves']))
         eng.close()
     (w1, b1, m1), (w0, b0, m0) = tables
-    assert np.array_equal(b1, b0) and m1 == m0 == 2 * B
+    assert np.array_equal(b1, b0) and m1 == m0 == 42 * B                    # 40 random + 2 TD steps per lane
     base = formulas.weights(n, scale=2.0 ** -4).astype(np.float64)
     moved = np.abs(w0 - base)
     assert moved.max() > 0
-    assert np.abs(w1 - w0).max() <= 1e-5 * (1.0 + moved.max())
+    # the hottest slot takes up to 8 * B adds; summed one by one in fp32 (mode 0) the rounding noise is about
+    # eps * |sum| * sqrt(adds), the LDS-owner path sums hierarchically and is more accurate: allow 4x that
+    assert np.abs(w1 - w0).max() <= 2.0 ** -23 * moved.max() * 4.0 * np.sqrt(8.0 * B)
 
 
 def test_td_auto_reset_and_stats_consistency():

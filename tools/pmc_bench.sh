@@ -1,0 +1,21 @@
+#!/bin/bash
+# rocprofv3 PMC pass (counters only, no trace domains) of the bench command; one CSV per call
+set -e
+cd /tmp && export TMPDIR=/tmp
+NAME=$1; shift
+PMC=$1; shift
+OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_$NAME
+rm -rf $OUT && mkdir -p $OUT
+cd $GRAFT_REPO_ROOT
+rocprofv3 --pmc $PMC --output-format csv -d $OUT -- python3 bench.py --steps 10 --warmup 10 --no-cpu-baseline "$@" > $OUT/bench.log 2>&1
+F=$(find $OUT -name "*counter_collection.csv" | head -1)
+python3 - "$F" <<'PY'
+import csv, sys, collections
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+with open(sys.argv[1]) as f:
+    for row in csv.DictReader(f):
+        k = row['Kernel_Name'].split('(')[0][-40:]
+        agg[k][row['Counter_Name']].append(float(row['Counter_Value']))
+for k, d in agg.items():
+    print(k, {c: (len(v), sum(v) / len(v)) for c, v in d.items()})
+PY
