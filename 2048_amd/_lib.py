@@ -38,6 +38,7 @@ SIGNATURES = {
     'g2048_table_slots': (c_int64, [c_int]),
     'g2048_feature_layout': (c_int, [c_int, _P, _P]),
     'g2048_create': (c_int, [c_int, c_uint32, c_int, c_uint64, c_uint64, POINTER(_P)]),
+    'g2048_create_shared': (c_int, [_P, c_uint32, c_uint64, c_uint64, POINTER(_P)]),
     'g2048_destroy': (c_int, [_P]),
     'g2048_last_error': (c_char_p, [_P]),
     'g2048_sync': (c_int, [_P]),
@@ -68,6 +69,7 @@ SIGNATURES = {
     'g2048_update': (c_int, [_P, _P, _P, c_int64]),
     'g2048_td_steps': (c_int, [_P, c_float, c_uint32]),
     'g2048_set_update_mode': (c_int, [_P, c_int]),
+    'g2048_get_last_move': (c_int, [_P, _P]),
     'g2048_stats_get': (c_int, [_P, POINTER(Stats)]),
     'g2048_stats_reset': (c_int, [_P]),
     'g2048_weights_device_ptr': (c_int, [_P, POINTER(_P), POINTER(c_int64)]),

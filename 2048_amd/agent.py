@@ -1,0 +1,501 @@
+"""`QAgent` (alias `Q_agent`) — the reference's n-tuple TD(0) learner (game2048/r_learning.py:85-406) on the device.
+
+Same constructor, attributes and methods as the reference; the table lives in HBM as one flat fp32 array
+(feature-major, weight_signature group order) and every piece of the hot path — f_n encoding, evaluate, greedy
+choice, update over the 8 symmetries, whole episodes — runs in the HIP kernels behind include/g2048.h.
+Added keyword arguments: `batch` (concurrent episodes used by train_run / trial; 1 = the reference's one game at a
+time), `seed`, `device`.
+
+Batched TD (batch > 1) is synchronous: in one board-step every lane chooses with the same table, then all
+(state, dw) records are added.  One slot can receive the adds of all 8 images of every lane in the same step, so
+the per-game learning rate is divided accordingly: alpha_device = alpha * num_feat / (8 * batch)   (DESIGN.md).
+"""
+from .game import *  # noqa: F401,F403  (r_learning.py:3 star-imports game_logic the same way)
+from .game import Game, np, pickle, time, deque, load_s3, save_s3, Logger, AGENT_PANE, RUNNING, dash_intervals
+
+from .engine import Engine, NUM_FEAT, feature_layout
+
+
+def check_thread(parent, benchmark):               # r_learning.py:6-13: "is the browser still there" heartbeat
+    now = time.time()
+    if (now - benchmark) > 2 * dash_intervals['check_run']:
+        if RUNNING[parent] == 0:
+            return 0
+        RUNNING[parent] = 0
+        return now
+    return benchmark
+
+
+# ---- n-tuple encoders f_2 .. f_6 (r_learning.py:17-69), computed by k_features on the device
+
+_FEATURE_ENGINES = {}
+
+
+def _features(n, x):
+    eng = _FEATURE_ENGINES.get(n)
+    if eng is None:
+        eng = _FEATURE_ENGINES[n] = _TableFree(n)
+    return eng(x)
+
+
+class _TableFree:
+    """A 1-lane context used only for g2048_features (the table stays untouched: the n=6 one is 383 MB, so the
+    context is created once per n and kept)."""
+
+    def __init__(self, n):
+        self.eng = Engine(1, n=n)
+
+    def __call__(self, x):
+        self.eng.set_boards(np.asarray(x, dtype=np.uint8).reshape(1, 4, 4))
+        return self.eng.features()[0].astype(np.int64)
+
+
+def f_2(x):
+    return _features(2, x)
+
+
+def f_3(x):
+    return _features(3, x)
+
+
+def f_4(x):
+    return _features(4, x)
+
+
+def f_5(x):
+    return _features(5, x)
+
+
+def f_6(x):
+    return _features(6, x)
+
+
+GROUPS = {2: (24,), 3: (52,), 4: (17,), 5: (17, 4), 6: (17, 4, 12)}       # weight_signature, r_learning.py:136-149
+
+
+class QAgent:
+
+    feature_functions = {2: f_2, 3: f_3, 4: f_4, 5: f_5, 6: f_6}                                       # r_learning.py:87
+    parameter_shape = {2: (24, 16 ** 2), 3: (52, 16 ** 3), 4: (17, 16 ** 4), 5: (21, 16 ** 5), 6: (33, 0)}     # :88
+
+    def __init__(self, name='agent', config_file=None, storage='s3', console='web', log_file=None, n=4, alpha=0.25,
+                 decay=0.75, decay_step=10000, low_alpha_limit=0.01, with_weights=True, batch=1, seed=2048, device=0):
+        # basic params (r_learning.py:93-99)
+        self.name = name
+        self.file = name + '.pkl'
+        self.game_file = 'best_of_' + self.file
+        self.s3 = (storage == 's3')
+        self.log_file = log_file
+        self.print = print if (console == 'local' or log_file is None) else Logger(log_file=log_file).add
+        # params from config file or init/defaults (r_learning.py:101-110)
+        config = (load_s3(config_file) or {}) if config_file else {}
+        self.n = config.get('n', n)
+        self.alpha = config.get('alpha', alpha)
+        self.decay = config.get('decay', decay)
+        self.decay_step = config.get('decay_step', decay_step)
+        self.low_alpha_limit = config.get('low_alpha_limit', low_alpha_limit)
+        # derived params (r_learning.py:112-114)
+        self.num_feat, self.size_feat = QAgent.parameter_shape[self.n]
+        self.features = QAgent.feature_functions[self.n]
+        # operational params (r_learning.py:116-122)
+        self.step = 0
+        self.top_game = None
+        self.top_score = 0
+        self.train_history = []
+        self.next_decay = self.decay_step
+        self.top_tile = 10
+        # device side
+        self.batch, self.seed, self.device = int(batch), int(seed), int(device)
+        self._engine = self._solo = None
+        self._pending_weights = None
+        self.weight_signature = None
+        if with_weights:
+            self.init_weights()
+
+    def __str__(self):
+        return f'Agent {self.name}, n={self.n}\ntrained for {self.step} episodes, top score = {self.top_score}'
+
+    # ---- device contexts
+
+    @property
+    def engine(self):
+        """The training batch (owns the weight table)."""
+        if self._engine is None:
+            self._engine = Engine(self.batch, n=self.n, seed=self.seed, device=self.device)
+            if self._pending_weights is not None:
+                self._engine.set_weights(self._pending_weights)
+                self._pending_weights = None
+        return self._engine
+
+    @property
+    def solo(self):
+        """One lane over the same table: evaluate / update of single boards and QAgent.episode."""
+        if self._solo is None:
+            self._solo = Engine(1, seed=self.seed + 0x5010, lane0=1 << 40, share_table_of=self.engine)
+            self._solo.set_auto_reset(False)
+        return self._solo
+
+    # ---- weights: a flat fp32 table on the device; `weights` shows it in the reference's list-of-rows form
+
+    def init_weights(self):
+        """U[0, 0.01) per slot (r_learning.py:136-149), drawn on the device."""
+        self.engine.init_weights(seed=np.random.randint(0, 2 ** 31), scale=0.01)
+        self.weight_signature = GROUPS[self.n]
+
+    @property
+    def weights(self):
+        if self._engine is None and self._pending_weights is None:
+            return None
+        flat = self.engine.get_weights()
+        offs, sizes = feature_layout(self.n)
+        return [flat[o:o + s] for o, s in zip(offs, sizes)]
+
+    @weights.setter
+    def weights(self, rows):
+        if rows is None:
+            return
+        flat = np.concatenate([np.asarray(r, dtype=np.float32).reshape(-1) for r in rows])
+        if self._engine is None:
+            self._pending_weights = flat
+        else:
+            self._engine.set_weights(flat)
+        self.weight_signature = GROUPS[self.n]
+
+    def list_to_np(self):
+        """Weights as one float32 array per weight_signature group — the on-disk form (r_learning.py:151-158)."""
+        rows = self.weights
+        out, start = [], 0
+        for d in self.weight_signature:
+            out.append(np.stack(rows[start:start + d]).astype(np.float32))
+            start += d
+        return out
+
+    def np_to_list(self):
+        """Inverse of list_to_np (r_learning.py:160-164); a no-op here, rows are always views of the flat table."""
+
+    # ---- persistence (r_learning.py:166-200): parameters and weights are stored separately in 's3' mode
+
+    def __getstate__(self):
+        state = {k: v for k, v in self.__dict__.items() if k not in ('_engine', '_solo', '_pending_weights', 'print')}
+        state['weights'] = self.list_to_np() if (self._engine is not None or self._pending_weights is not None) else None
+        return state
+
+    def __setstate__(self, state):
+        groups = state.pop('weights', None)
+        self.__dict__.update(state)
+        self.__dict__.setdefault('batch', 1)
+        self.__dict__.setdefault('seed', 2048)
+        self.__dict__.setdefault('device', 0)
+        self._engine = self._solo = self._pending_weights = None
+        self.print = print
+        self.features = QAgent.feature_functions[self.n]
+        if groups is not None:
+            self.weights = [row for g in groups for row in np.asarray(g)]
+
+    def save_agent(self):
+        if self.s3:
+            nps = self.list_to_np()
+            params = QAgent(name=self.name, with_weights=False)
+            for key, value in self.__dict__.items():
+                if key not in ('_engine', '_solo', '_pending_weights'):
+                    setattr(params, key, value)
+            save_s3(params, 'a/' + self.file)
+            save_s3(nps, 'weights/' + self.file)
+        else:
+            with open(self.file, 'wb') as f:
+                pickle.dump(self, f, -1)
+
+    def save_game(self, game):
+        if self.s3:
+            save_s3(game, 'g/' + self.game_file)
+        else:
+            game.save_game(self.game_file)
+
+    @staticmethod
+    def load_agent_local(file):
+        with open(file, 'rb') as f:           # (the reference opens in text mode, r_learning.py:190 — a bug)
+            return pickle.load(f)
+
+    @staticmethod
+    def load_agent(file):
+        agent = load_s3(file)
+        groups = load_s3(f'weights/{file[2:]}')
+        agent.weights = [row for g in groups for row in np.asarray(g)]
+        return agent
+
+    # ---- value and update of one board (r_learning.py:202-214)
+
+    def evaluate(self, row, score=None):
+        self.solo.set_boards(np.asarray(row, dtype=np.uint8).reshape(1, 4, 4), clear_carry=False)
+        return float(self.solo.evaluate()[0])
+
+    def update(self, row, dw):
+        self.engine.update(np.asarray(row, dtype=np.uint8).reshape(1, 4, 4), np.array([dw], np.float32))
+
+    # ---- one self-play game with online TD(0) (r_learning.py:224-252), on the solo lane
+
+    def episode(self):
+        solo = self.solo
+        solo.reset()
+        solo.clear_carry()
+        game = Game(row=solo.get_boards()[0])
+        game.starting_position = game.row.copy()
+        while True:
+            solo.td_steps(self.alpha, 1)
+            lm = int(solo.last_move()[0])
+            if not lm & 4:
+                break
+            game.moves.append(lm & 3)
+            game.odometer += 1
+            if lm & (1 << 10):
+                cell = (lm >> 4) & 15
+                game.tiles.append(((lm >> 8) & 3, (cell >> 2, cell & 3)))
+            if lm & (1 << 11):
+                break
+        game.row = solo.get_boards()[0].astype(np.int32)
+        game.score = int(solo.get_scores()[0])
+        game.moves.append(-1)
+        self.step += 1
+        return game
+
+    def _display_lr(self):
+        self.print(f'episode = {self.step + 1}, current learning rate = {round(self.alpha, 4)}:')
+
+    def decay_alpha(self):                                           # r_learning.py:257-262
+        self.alpha = round(max(self.alpha * self.decay, self.low_alpha_limit), 4)
+        self.next_decay = self.step + self.decay_step
+        self.print('------')
+        self._display_lr()
+        self.print('------')
+
+    # ---- training loop (r_learning.py:269-346)
+
+    def train_run(self, num_eps=100000, add_weights='already', saving=True, stopper=None):
+        if add_weights == 'add':
+            self.init_weights()
+        elif add_weights != 'already':
+            self.print('loading weights ...')
+            groups = load_s3(add_weights)
+            self.weights = [row for g in groups for row in np.asarray(g)]
+        if self.batch > 1:
+            return self._train_run_batched(num_eps, saving, stopper)
+        if stopper:
+            parent, this_thread = stopper['parent'], stopper['a']
+        av1000, ma100 = [], deque(maxlen=100)
+        reached = [0] * 7
+        best_of_1000 = None
+        global_start = start = benchmark_time = time.time()
+        self.print(f'Agent {self.name} training session started, current step = {self.step}')
+        self.print('Agent will be saved every 1000 episodes and on STOP command')
+        for i in range(self.step + 1, self.step + num_eps + 2):
+            if stopper:
+                if AGENT_PANE[parent]['id'] != this_thread:
+                    break
+                benchmark_time = check_thread(parent, benchmark_time)
+                if not benchmark_time:
+                    return
+            if self.step > self.next_decay and self.alpha > self.low_alpha_limit:
+                self.decay_alpha()
+            game = self.episode()
+            ma100.append(game.score)
+            av1000.append(game.score)
+            if best_of_1000 is None or game.score > best_of_1000.score:
+                best_of_1000 = game
+                if game.score > self.top_score:
+                    self.top_game, self.top_score = game, game.score
+                    self.print(f'\nnew best game at episode {i}!\n{game}\n')
+                    if saving:
+                        self.save_game(game)
+                        self.print(f'game saved at {self.game_file}')
+            max_tile = int(np.max(game.row))
+            if max_tile >= 10:
+                reached[min(max_tile, 16) - 10] += 1
+            if max_tile > self.top_tile:                             # new maximum tile: decay (r_learning.py:311-313)
+                self.top_tile = max_tile
+                self.decay_alpha()
+            if i % 100 == 0:
+                ma = int(np.mean(ma100))
+                self.train_history.append(ma)
+                self.print(f'episode {i}: score {game.score} reached {1 << max_tile} ma_100 = {ma}')
+            if i % 1000 == 0:
+                self._report_1000(i, np.mean(av1000), reached, best_of_1000, time.time() - start, saving)
+                start, av1000, reached, best_of_1000 = time.time(), [], [0] * 7, None
+        self._finish(global_start, saving)
+
+    def _report_1000(self, i, average, reached, best, seconds, saving):     # r_learning.py:318-341
+        self.print('\n------')
+        self.print(f'{round(seconds / 60, 2)} min')
+        self.print(f'episode = {i}')
+        self.print(f'average over last 1000 episodes = {average}')
+        total = max(1, sum(reached)) if sum(reached) > 1000 else 1000
+        for j in range(7):
+            r = sum(reached[j:]) / (total / 100)
+            if r:
+                self.print(f'{1 << (j + 10)} reached in {r} %')
+        if best is not None:
+            self.print('best of last 1000:')
+            self.print(str(best))
+        if self.top_game is not None:
+            self.print('best of this Agent:')
+            self.print(str(self.top_game))
+        self._display_lr()
+        self.print('------\n')
+        if saving:
+            self.save_agent()
+            self.print(f'agent saved in {self.file}')
+
+    def _finish(self, global_start, saving):                         # r_learning.py:342-346
+        total_time = int(time.time() - global_start)
+        self.print(f'Total time = {total_time // 60} min {total_time % 60} sec')
+        if saving:
+            self.save_agent()
+            self.print(f'{self.name} saved at step {self.step} in {self.file}\n------------------------\n')
+
+    def device_alpha(self, lanes=None):
+        """The batch rule: alpha for g2048_td_steps when `lanes` episodes learn concurrently."""
+        lanes = self.batch if lanes is None else lanes
+        return self.alpha if lanes == 1 else self.alpha * self.num_feat / (8.0 * lanes)
+
+    def _train_run_batched(self, num_eps, saving, stopper, chunk=64):
+        """train_run on `batch` concurrent episodes: the same schedule and logs, driven by the device's episode
+        counters.  Per-game records (best game, exact ma_100 of consecutive games) need per-lane logs and are
+        not kept here; averages are over the games that finished in each reporting window."""
+        eng = self.engine
+        eng.set_auto_reset(True)
+        if stopper:
+            parent, this_thread = stopper['parent'], stopper['a']
+        global_start = start = benchmark_time = time.time()
+        self.print(f'Agent {self.name} training session started, current step = {self.step}, {self.batch} concurrent episodes')
+        eng.stats_reset()
+        base = self.step
+        last = eng.stats()
+        mark100, mark1000 = dict(last), dict(last)
+        next100 = (self.step // 100 + 1) * 100
+        next1000 = (self.step // 1000 + 1) * 1000
+        target = self.step + num_eps + 1
+        while self.step < target:
+            if stopper:
+                if AGENT_PANE[parent]['id'] != this_thread:
+                    break
+                benchmark_time = check_thread(parent, benchmark_time)
+                if not benchmark_time:
+                    return
+            if self.step > self.next_decay and self.alpha > self.low_alpha_limit:
+                self.decay_alpha()
+            eng.td_steps(self.device_alpha(), chunk)
+            st = eng.stats()
+            self.step = base + st['episodes']
+            self.top_score = max(self.top_score, st['best_score'])
+            top = max([t for t, cnt in enumerate(st['max_tile']) if cnt] or [0])
+            if top > self.top_tile:
+                self.top_tile = top
+                self.decay_alpha()
+            while self.step >= next100:
+                done = st['episodes'] - mark100['episodes']
+                ma = int((st['score_sum'] - mark100['score_sum']) / max(1, done))
+                self.train_history.append(ma)
+                self.print(f'episode {next100}: ma_100 = {ma} (mean of the {done} games finished since the last report)')
+                mark100, next100 = dict(st), next100 + 100 * max(1, (self.step - next100) // 100 + 1)
+            if self.step >= next1000:
+                done = st['episodes'] - mark1000['episodes']
+                hist = [a - b for a, b in zip(st['max_tile'], mark1000['max_tile'])]
+                reached = [sum(hist[10 + j:10 + j + 1]) for j in range(6)] + [sum(hist[16:])]
+                average = (st['score_sum'] - mark1000['score_sum']) / max(1, done)
+                self._report_1000(self.step, average, [r * 1000 / max(1, done) for r in reached], None, time.time() - start, saving)
+                start, mark1000, next1000 = time.time(), dict(st), (self.step // 1000 + 1) * 1000
+        self._finish(global_start, saving)
+
+    # ---- evaluation harness (r_learning.py:348-406)
+
+    @staticmethod
+    def trial(estimator=None, agent_file=None, limit_tile=0, num=20, game_init=None, depth=0, width=1, since_empty=6,
+              storage='s3', console='local', log_file=None, game_file=None, verbose=False, stopper=None):
+        display = print if console == 'local' else Logger(log_file=log_file).add
+        if stopper:
+            parent, this_thread = stopper['parent'], stopper['a']
+        if agent_file:
+            display(f'Loading Agent from {agent_file} ...')
+            agent = QAgent.load_agent(agent_file)
+            estimator = agent.evaluate
+            display(f'Trial run for {num} games, Agent = {agent.name}\n'
+                    f'Looking forward: depth={depth}, width={width}, since_empty={since_empty}')
+        start = benchmark_time = time.time()
+        owner = getattr(estimator, '__self__', None)
+        shuffles = Game.counter
+        if isinstance(owner, QAgent) and depth == 0 and not limit_tile and not verbose and not stopper:
+            results, shuffles = owner._trial_batched(num, game_init), 0
+            for i, game in enumerate(results):
+                display(f'game {i}, result {game.score}, moves {game.odometer}, achieved {1 << np.max(game.row)}')
+        else:
+            results = []
+            for i in range(num):
+                if stopper:
+                    if AGENT_PANE[parent]['id'] != this_thread:
+                        break
+                    benchmark_time = check_thread(parent, benchmark_time)
+                    if not benchmark_time:
+                        return
+                now = time.time()
+                game = Game() if game_init is None else game_init.copy()
+                game.trial_run(estimator, limit_tile=limit_tile, depth=depth, width=width, since_empty=since_empty,
+                               verbose=verbose)
+                display(f'game {i}, result {game.score}, moves {game.odometer}, achieved {1 << np.max(game.row)}, '
+                        f'time = {(time.time() - now):.2f}')
+                results.append(game)
+            shuffles = Game.counter
+        if not results:
+            return
+        average = np.average([v.score for v in results])
+        figures = [(1 << np.max(v.row)) for v in results]
+        total_odo = sum([v.odometer for v in results])
+        results.sort(key=lambda v: v.score, reverse=True)
+
+        def share(limit):
+            return len([0 for v in figures if v >= limit]) / len(figures) * 100
+
+        elapsed = time.time() - start
+        message = '\nBest games:\n' + ''.join(str(v) + '\n\n' for v in results[:3])
+        message += f'average score of {len(results)} runs = {average}\n'
+        for limit in (16384, 8192, 4096, 2048, 1024):
+            message += f'{limit} reached in {share(limit)}%\n'
+        message += f'total time = {round(elapsed, 2)}\naverage time per move = {round(elapsed / max(1, total_odo) * 1000, 2)} ms\n'
+        if shuffles:
+            message += f'total number of shuffles = {shuffles}\ntime per shuffle = {round(elapsed / shuffles * 1000, 2)} ms'
+        display(message)
+        if game_file:
+            if storage == 's3':
+                save_s3(results[0], game_file)
+            else:
+                results[0].save_game(file=game_file)
+            display(f'Best game saved at {game_file}\n------------------------\n')
+        return results
+
+    def _trial_batched(self, num, game_init=None):
+        """`num` greedy games at once on the device (alpha = 0: no records, no learning), each to its end."""
+        eng = Engine(num, seed=self.seed + 77, lane0=1 << 41, share_table_of=self.engine)
+        eng.set_auto_reset(False)
+        if game_init is not None:
+            eng.set_boards(np.repeat(np.asarray(game_init.row, np.uint8)[None], num, axis=0))
+            eng.set_scores(np.full(num, game_init.score, np.int32))
+        start_boards = eng.get_boards()
+        odometer = np.zeros(num, np.int64)
+        while True:
+            eng.td_steps(0.0, 1)
+            lm = eng.last_move()
+            odometer += (lm >> 2) & 1
+            if not ((lm >> 2) & 1).any():
+                break
+        boards, scores = eng.get_boards(), eng.get_scores()
+        eng.close()
+        games = []
+        for i in range(num):
+            g = Game(score=int(scores[i]), row=boards[i])
+            g.starting_position = start_boards[i].astype(np.int32)
+            g.odometer = int(odometer[i])
+            games.append(g)
+        return games
+
+
+Q_agent = QAgent          # the name used by the reference's README (README.md:62-65)
+
+__all__ = [n for n in dir() if not n.startswith('_')]

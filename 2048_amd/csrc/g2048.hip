@@ -391,7 +391,7 @@ __device__ __forceinline__ void push_terminal(const TdRecs& r, const Packed& sta
 template <int N>
 __global__ __launch_bounds__(WG) void k_td_play(uint4* boards, int32_t* scores, ulonglong2* rng, uint4* prev_nxt, float* label, uint8_t* flags,
                                                 uint32_t B, const float* __restrict__ w, float alpha, TdRecs recs, int auto_reset,
-                                                Stats* stats) {
+                                                Stats* stats, uint16_t* last_move) {
     constexpr float F = (float)Shape<N>::F;
     uint32_t i = blockIdx.x * WG + threadIdx.x;
     if (i == 0) *recs.qcount_next = 0;
@@ -399,6 +399,7 @@ __global__ __launch_bounds__(WG) void k_td_play(uint4* boards, int32_t* scores, 
     if (i < B) {
         uint8_t fl = flags[i];
         float dw1 = 0.0f;
+        uint32_t lm = 0;        // what this lane did: bits 0-1 direction, 2 moved, 4-7 new tile's cell, 8-9 new tile, 10 spawned, 11 game ended
         if (!(fl & DONE)) {
             Board b = ld_board(boards, i);
             Rng g = ld_rng(rng, i);
@@ -418,7 +419,17 @@ __global__ __launch_bounds__(WG) void k_td_play(uint4* boards, int32_t* scores, 
                 fl |= HAS_PREV;
                 moved = true;
                 b = ch.after;
-                spawn(b, g);
+                lm = (uint32_t)c.action | 4u;
+                if (spawn(b, g)) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const uint32_t d = b.r[r] ^ ch.after.r[r];          // the one byte that changed
+                        if (d) {
+                            const uint32_t col = (uint32_t)(__ffs((int)d) - 1) >> 3;
+                            lm |= ((uint32_t)(4 * r) + col) << 4 | ((d >> (8 * col)) & 3u) << 8 | 1u << 10;
+                        }
+                    }
+                }
                 overflow = max_tile(b) >= 16u;
                 over = game_over(b) || overflow;
                 if (over) push_terminal(recs, after, -c.value * alpha / F);
@@ -429,6 +440,7 @@ __global__ __launch_bounds__(WG) void k_td_play(uint4* boards, int32_t* scores, 
                 if (fl & HAS_PREV) push_terminal(recs, ld_packed(recs.state1, i), -old_label * alpha / F);
             }
             if (over) {
+                lm |= 1u << 11;
                 count_finished(stats, b, score, overflow);
                 if (auto_reset) {
                     b = new_game(g);
@@ -446,6 +458,7 @@ __global__ __launch_bounds__(WG) void k_td_play(uint4* boards, int32_t* scores, 
             flags[i] = fl;
         }
         recs.dw1[i] = dw1;
+        last_move[i] = (uint16_t)lm;
     }
     count_moves(stats, moved);
 }
@@ -727,6 +740,7 @@ struct g2048_ctx {
     uint4* qstate = nullptr;            // terminal-record queue
     float* qdw = nullptr;
     uint32_t* qcount = nullptr;         // [2]: this step's / next step's queue length
+    uint16_t* last_move = nullptr;      // what every lane did in the latest TD step (g2048_get_last_move)
     uint32_t step_parity = 0;
     float *w = nullptr, *w0 = nullptr, *delta = nullptr;
     Stats* stats = nullptr;
@@ -739,6 +753,7 @@ struct g2048_ctx {
     float* D = nullptr;                 // per-orbit delta tables (n >= 4)
     OrbitTable orbits = {};
     int update_mode = 1;                // 1: LDS-owner update (default), 0: global fp32 atomics
+    bool owns_table = true;             // false: `w` belongs to the parent context (g2048_create_shared)
     void* scratch = nullptr;
     size_t scratch_bytes = 0;
     std::string err;
@@ -1022,7 +1037,7 @@ int launch_td_step(g2048_ctx* c, float alpha, hipEvent_t ev = nullptr) {
     recs.qcount = c->qcount + c->step_parity;
     recs.qcount_next = c->qcount + (c->step_parity ^ 1u);
     BY_N(c, (k_td_play<N><<<grid_for(B), WG, 0, c->stream>>>(c->boards, c->scores, c->rng, pn, c->label, c->flags, B, c->w, alpha, recs,
-                                                             c->auto_reset, c->stats)));
+                                                             c->auto_reset, c->stats, c->last_move)));
     if (ev) (void)hipEventRecord(ev, c->stream);
     if (c->update_mode == 1) {
         if (c->steps_since_plan >= c->replan_every)
@@ -1108,9 +1123,9 @@ int g2048_destroy(g2048_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* bufs[] = {c->boards, c->scores, c->rng, c->prev[0], c->prev[1], c->label, c->flags, c->dw1, c->qstate,
-                    c->qdw,    c->qcount, c->w,      c->w0,  c->delta,   c->stats,   c->scratch, c->slices, c->hits, c->D};
+                    c->qdw,    c->qcount, c->last_move, c->w,      c->w0,  c->delta,   c->stats,   c->scratch, c->slices, c->hits, c->D};
     for (void* p : bufs)
-        if (p) (void)hipFree(p);
+        if (p && (p != (void*)c->w || c->owns_table)) (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1118,7 +1133,7 @@ int g2048_destroy(g2048_ctx* c) {
     return G2048_OK;
 }
 
-int g2048_create(int device, uint32_t batch, int n_tuple, uint64_t seed, uint64_t lane0, g2048_ctx** out) {
+static int create_impl(int device, uint32_t batch, int n_tuple, uint64_t seed, uint64_t lane0, g2048_ctx* parent, g2048_ctx** out) {
     if (!out) return G2048_ERR_ARG;
     *out = nullptr;
     int F;
@@ -1152,16 +1167,21 @@ int g2048_create(int device, uint32_t batch, int n_tuple, uint64_t seed, uint64_
     if ((rc = dalloc(c, &c->boards, B)) || (rc = dalloc(c, &c->scores, B)) || (rc = dalloc(c, &c->rng, B)) ||
         (rc = dalloc(c, &c->prev[0], B)) || (rc = dalloc(c, &c->prev[1], B)) || (rc = dalloc(c, &c->label, B)) ||
         (rc = dalloc(c, &c->flags, B)) || (rc = dalloc(c, &c->dw1, B)) || (rc = dalloc(c, &c->qstate, B)) || (rc = dalloc(c, &c->qdw, B)) ||
-        (rc = dalloc(c, &c->qcount, 2)) ||
+        (rc = dalloc(c, &c->qcount, 2)) || (rc = dalloc(c, &c->last_move, B)) ||
         (rc = dalloc(c, &c->stats, 1)))
         return bail(rc);
-    if (slots && (rc = dalloc(c, &c->w, slots))) return bail(rc);
+    if (parent) {
+        c->w = parent->w;
+        c->owns_table = false;
+    } else if (slots && (rc = dalloc(c, &c->w, slots))) {
+        return bail(rc);
+    }
     if ((rc = build_slices(c))) return bail(rc);
     if (hipMemsetAsync(c->stats, 0, sizeof(Stats), c->stream) != hipSuccess ||
         hipMemsetAsync(c->prev[0], 0, B * sizeof(uint4), c->stream) != hipSuccess ||
         hipMemsetAsync(c->prev[1], 0, B * sizeof(uint4), c->stream) != hipSuccess ||
-        hipMemsetAsync(c->qcount, 0, 8, c->stream) != hipSuccess || hipMemsetAsync(c->dw1, 0, B * 4, c->stream) != hipSuccess ||
-        (slots && hipMemsetAsync(c->w, 0, slots * sizeof(float), c->stream) != hipSuccess))
+        hipMemsetAsync(c->qcount, 0, 8, c->stream) != hipSuccess || hipMemsetAsync(c->last_move, 0, B * 2, c->stream) != hipSuccess || hipMemsetAsync(c->dw1, 0, B * 4, c->stream) != hipSuccess ||
+        (slots && !parent && hipMemsetAsync(c->w, 0, slots * sizeof(float), c->stream) != hipSuccess))
         return bail(G2048_ERR_HIP);
     k_seed<<<grid_for(B), WG, 0, c->stream>>>(c->rng, batch, seed, lane0);
     k_new_games<<<grid_for(B), WG, 0, c->stream>>>(c->boards, c->scores, c->rng, c->label, c->flags, batch);
@@ -1171,6 +1191,15 @@ int g2048_create(int device, uint32_t batch, int n_tuple, uint64_t seed, uint64_
     }
     *out = c;
     return G2048_OK;
+}
+
+int g2048_create(int device, uint32_t batch, int n_tuple, uint64_t seed, uint64_t lane0, g2048_ctx** out) {
+    return create_impl(device, batch, n_tuple, seed, lane0, nullptr, out);
+}
+
+int g2048_create_shared(g2048_ctx* parent, uint32_t batch, uint64_t seed, uint64_t lane0, g2048_ctx** out) {
+    if (!parent || parent->n == 0) return G2048_ERR_ARG;
+    return create_impl(parent->device, batch, parent->n, seed, lane0, parent, out);
 }
 
 int g2048_sync(g2048_ctx* c) {
@@ -1450,6 +1479,12 @@ int g2048_td_steps_profiled(g2048_ctx* c, float alpha, uint32_t nsteps, float* m
     *ms_play = nsteps ? (float)(tp / nsteps) : 0.0f;
     *ms_update = nsteps ? (float)(tu / nsteps) : 0.0f;
     return launched(c, "k_td_play/k_td_update");
+}
+
+int g2048_get_last_move(g2048_ctx* c, uint16_t* out) {
+    if (!c || !out) return c ? fail(c, G2048_ERR_ARG, "null buffer") : G2048_ERR_ARG;
+    if (int rc = bind(c)) return rc;
+    return d2h(c, out, c->last_move, (size_t)c->B * 2);
 }
 
 int g2048_stats_get(g2048_ctx* c, g2048_stats* out) {

@@ -30,13 +30,20 @@ def feature_layout(n):
 
 
 class Engine:
-    def __init__(self, batch, n=0, seed=2048, lane0=0, device=0):
+    def __init__(self, batch, n=0, seed=2048, lane0=0, device=0, share_table_of=None):
+        """share_table_of: another Engine whose weight table this one uses (g2048_create_shared)."""
         self.lib = _lib.load()
+        if share_table_of is not None:
+            n, device = share_table_of.n, share_table_of.device
         self.batch, self.n, self.seed, self.lane0, self.device = int(batch), int(n), int(seed), int(lane0), int(device)
         self.num_feat = NUM_FEAT.get(self.n, 0)
         self.slots = table_slots(self.n) if self.n else 0
+        self.parent = share_table_of                      # keeps the table's owner alive
         ctx = ctypes.c_void_p()
-        check(self.lib.g2048_create(self.device, self.batch, self.n, self.seed & (2 ** 64 - 1), self.lane0, ctypes.byref(ctx)))
+        if share_table_of is None:
+            check(self.lib.g2048_create(self.device, self.batch, self.n, self.seed & (2 ** 64 - 1), self.lane0, ctypes.byref(ctx)))
+        else:
+            check(self.lib.g2048_create_shared(share_table_of.ctx, self.batch, self.seed & (2 ** 64 - 1), self.lane0, ctypes.byref(ctx)))
         self.ctx = ctx
 
     def close(self):
@@ -170,6 +177,12 @@ class Engine:
 
     def td_steps(self, alpha, nsteps=1):
         self._c(self.lib.g2048_td_steps(self.ctx, float(alpha), int(nsteps)))
+
+    def last_move(self):
+        """uint16[B], see g2048_get_last_move: direction | moved<<2 | cell<<4 | tile<<8 | spawned<<10 | ended<<11."""
+        out = np.empty(self.batch, np.uint16)
+        self._c(self.lib.g2048_get_last_move(self.ctx, _buf(out)))
+        return out
 
     def set_update_mode(self, mode):
         """1 = LDS-owner update kernel (default), 0 = global fp32 atomics."""

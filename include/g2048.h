@@ -61,6 +61,10 @@ int g2048_feature_layout(int n_tuple, int64_t* offsets, int64_t* sizes); /* per-
 /* ---- lifecycle.  n_tuple in {0 (environment only), 2, 3, 4, 5, 6}.  Lanes are seeded from
  * splitmix64(seed + lane0 + lane) and start as fresh games (Game.__init__, game_logic.py:55-66). */
 int g2048_create(int device, uint32_t batch, int n_tuple, uint64_t seed, uint64_t lane0, g2048_ctx** out);
+/* A second set of lanes over the SAME weight table as `parent` (same device, same n-tuple): e.g. one lane for
+ * QAgent.episode / evaluate next to the big training batch.  The parent must outlive it; the caller serialises
+ * calls on contexts that share a table. */
+int g2048_create_shared(g2048_ctx* parent, uint32_t batch, uint64_t seed, uint64_t lane0, g2048_ctx** out);
 int g2048_destroy(g2048_ctx* ctx);
 const char* g2048_last_error(const g2048_ctx* ctx);
 int g2048_sync(g2048_ctx* ctx);
@@ -117,6 +121,10 @@ int g2048_set_update_mode(g2048_ctx* ctx, int mode);
 /* the same, with HIP events around each of the step's two kernels (synchronises every step): average
  * milliseconds per launch of k_td_play and k_td_update, for the roofline line of bench.py */
 int g2048_td_steps_profiled(g2048_ctx* ctx, float alpha, uint32_t nsteps, float* ms_play, float* ms_update);
+/* what every lane did in the latest TD step — the entries Game.moves / Game.tiles get in QAgent.episode
+ * (r_learning.py:244, game_logic.py:121): bits 0-1 direction, bit 2 a move was made, bits 4-7 cell (4*r + c) of
+ * the new tile, bits 8-9 the new tile (1 or 2), bit 10 a tile was placed, bit 11 the game ended on this step. */
+int g2048_get_last_move(g2048_ctx* ctx, uint16_t* out /* [B] */);
 int g2048_stats_get(g2048_ctx* ctx, g2048_stats* out);
 int g2048_stats_reset(g2048_ctx* ctx);
 

@@ -1,0 +1,102 @@
+"""Host-side checks that need no GPU: the C ABI library loads and exports every symbol include/g2048.h declares,
+the product fails loudly without a GPU (no CPU fallback), the reference-shaped surface imports, lane sharding."""
+import ctypes
+import importlib
+import os
+import pickle
+import re
+
+import numpy as np
+import pytest
+
+from tests.conftest import ROOT
+
+pkg = importlib.import_module('2048_amd')
+_lib = importlib.import_module('2048_amd._lib')
+parallel = importlib.import_module('2048_amd.parallel')
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, 'include', 'g2048.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(g2048_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_library_exports_every_declared_symbol():
+    names = header_functions()
+    assert len(names) >= 40
+    lib = ctypes.CDLL(_lib.LIB_PATH)                        # built by __graft_entry__.build()
+    for name in names:
+        assert hasattr(lib, name), f'{name} is declared in include/g2048.h but not exported by lib2048_hip.so'
+        assert name in _lib.SIGNATURES, f'{name} has no ctypes signature in 2048_amd/_lib.py'
+    assert set(_lib.SIGNATURES) <= set(names)
+    lib = pkg.load_library()
+    assert lib.g2048_abi_version() == 1
+    assert [lib.g2048_num_feat(n) for n in (2, 3, 4, 5, 6)] == [24, 52, 17, 21, 33]
+    assert lib.g2048_num_feat(7) == -1
+    assert [lib.g2048_table_slots(n) for n in (2, 3, 4, 5, 6)] == [6144, 212992, 1114112, 5308416, 95662848]
+    offs, sizes = importlib.import_module('2048_amd.engine').feature_layout(6)
+    assert offs[17] == 17 * 65536 and offs[21] == 17 * 65536 + 4 * 2 ** 20 and sizes[32] == 14 ** 6
+    assert lib.g2048_strerror(-5) == b'no usable GPU'
+
+
+def test_no_gpu_means_loud_failure_not_a_cpu_path():
+    n = ctypes.c_int(-1)
+    pkg.load_library().g2048_device_count(ctypes.byref(n))
+    if n.value > 0:
+        pytest.skip('a GPU is present')
+    with pytest.raises(_lib.G2048Error) as e:
+        pkg.Engine(16, n=2)
+    assert e.value.status == _lib.ERR_NODEV
+    gl = importlib.import_module('game2048.game_logic')
+    g = gl.Game(row=np.zeros((4, 4), np.int32))
+    with pytest.raises(_lib.G2048Error):                    # moving a board needs the device
+        g.pre_move(g.row, 0, 0)
+    # and nothing in the product imports the oracle
+    for root, _, files in os.walk(os.path.join(ROOT, '2048_amd')):
+        for f in files:
+            if f.endswith('.py'):
+                assert 'oracle' not in open(os.path.join(root, f)).read().replace('the oracle', ''), f
+    for f in os.listdir(os.path.join(ROOT, 'game2048')):
+        if f.endswith('.py'):
+            assert 'oracle' not in open(os.path.join(ROOT, 'game2048', f)).read()
+
+
+def test_reference_surface_is_importable_under_its_own_names():
+    ns = {}
+    exec('from game2048.r_learning import *', ns)            # what the reference's show.py does (show.py:4)
+    for name in ('Game', 'QAgent', 'Q_agent', 'f_2', 'f_6', 'random_eval', 'score_eval', 'load_s3', 'save_s3',
+                 'list_names_s3', 'Logger', 'np', 'pickle', 'GAME_PANE', 'AGENT_PANE', 'RUNNING'):
+        assert name in ns, name
+    Game, QAgent = ns['Game'], ns['QAgent']
+    assert Game.actions == {0: 'left', 1: 'up', 2: 'right', 3: 'down'}
+    assert QAgent.parameter_shape[5] == (21, 16 ** 5) and ns['Q_agent'] is QAgent
+    assert Game.__module__ == 'game2048.game_logic' and QAgent.__module__ == 'game2048.r_learning'
+    g = Game()                                               # two tiles, host-side record keeping only
+    assert np.count_nonzero(g.row) == 2 and g.tiles == [] and g.row.dtype == np.int32 and g.row[0, 0] >= 0
+    g2 = pickle.loads(pickle.dumps(g))
+    assert g2 == g and 'score = 0' in str(g)
+    a = QAgent(name='x', storage='local', console='local', n=4, with_weights=False)
+    assert (a.num_feat, a.n, a.alpha, a.decay, a.decay_step, a.low_alpha_limit) == (17, 4, 0.25, 0.75, 10000, 0.01)
+    assert a.weights is None and a.weight_signature is None
+    assert abs(QAgent(n=5, with_weights=False, batch=1 << 20).device_alpha() - 0.25 * 21 / (8 * 2 ** 20)) < 1e-12
+
+
+def test_shard_lanes_partitions_exactly():
+    for total, world in ((1 << 20, 8), (1000, 3), (7, 8), (1, 1)):
+        spans = [parallel.shard_lanes(total, r, world) for r in range(world)]
+        assert spans[0][0] == 0 and sum(c for _, c in spans) == total
+        for (a0, ac), (b0, _) in zip(spans, spans[1:]):
+            assert a0 + ac == b0
+        assert max(c for _, c in spans) - min(c for _, c in spans) <= 1
+
+
+def test_rng_spec_scalar_and_vector_agree():
+    rng = pkg.rng
+    st = rng.seed_lanes(99, 5, 8)
+    lanes = [rng.LaneRng(99, 5 + i) for i in range(8)]
+    for _ in range(10):
+        u = rng.next_u64_np(st)
+        assert [int(v) for v in u] == [l.next() for l in lanes]
+    r10, k = rng.spawn_draw_np(u, np.full(8, 7))
+    assert [(int(a), int(b)) for a, b in zip(r10, k)] == [rng.spawn_draw(int(v), 7) for v in u]

@@ -1,0 +1,138 @@
+"""The reference-shaped Python surface (game2048.game_logic.Game, game2048.r_learning.QAgent) on the device:
+what show.py / application.py call must behave as the reference does."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+from oracle import ref_batch as rb
+from oracle import ref_scalar as rs
+from tests.golden import formulas
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def api():
+    import game2048.r_learning as rl
+    return rl
+
+
+def test_game_moves_terminal_and_table(api, golden):
+    g = golden('moves.npz')
+    game = api.Game(row=np.zeros((4, 4), np.int32))
+    for i in range(0, len(g['boards']), 53):
+        row = g['boards'][i].astype(np.int32)
+        for d in range(4):
+            new_row, new_score, changed = game.pre_move(row, 100, d)
+            assert new_row.dtype == np.int32 and np.array_equal(new_row, g['after'][i, d])
+            assert new_score == 100 + g['reward'][i, d] and changed == bool(g['changed'][i, d])
+        assert game.game_over(row) == bool(g['game_over'][i])
+        assert api.Game.empty_count(row) == g['empty_count'][i]
+        assert api.Game.adjacent_pair_count(row) == g['adjacent_pair_count'][i]
+    t = golden('move_table.npz')
+    table = api.Game.table                                     # built by the device on first access
+    assert len(table) == 65536
+    for key in (0x0000, 0x1111, 0x1120, 0x2022, 0xFFEE, 0x1234, 0x8008, 0xABBA):
+        line = ((key >> 12) & 15, (key >> 8) & 15, (key >> 4) & 15, key & 15)
+        assert table[line] == (tuple(int(v) for v in t['out'][key]), int(t['score'][key]) * int(t['changed'][key]), bool(t['changed'][key]))
+    before = api.Game.counter
+    game.pre_move(np.zeros((4, 4), np.int32), 0, 1)
+    assert api.Game.counter == before + 1
+
+
+def test_game_play_and_replay(api):
+    import random
+    random.seed(3)
+    game = api.Game()
+    start = game.row.copy()
+    game.trial_run(api.score_eval, step_limit=60)              # greedy on the score, 60 moves
+    assert game.odometer == 60 or game.game_over(game.row)
+    assert len(game.moves) == game.odometer == len(game.tiles)
+    game.moves.append(-1)
+    chain = game.replay(verbose=False)                         # the recorded game re-runs to the same position
+    assert np.array_equal(chain[0][0], start) and np.array_equal(chain[game.odometer][0], game.row)
+    assert chain[game.odometer][1] == game.score
+    runs = list(zip(range(5), api.Game().generate_run(api.random_eval)))
+    assert len(runs) == 5 and all(d in (0, 1, 2, 3) for _, (_, d) in runs)
+
+
+@pytest.mark.parametrize('n', [2, 4, 5])
+def test_agent_evaluate_update_features(api, golden, n):
+    g = golden('learner.npz')
+    agent = api.QAgent(name='t', storage='local', console='local', n=n, with_weights=False)
+    w = formulas.weights(n)
+    offs, total = rs.feature_offsets(n)
+    agent.weights = [w[o:o + s] for o, s in zip(offs, formulas.feature_sizes(n))]
+    assert agent.weight_signature == {2: (24,), 4: (17,), 5: (17, 4)}[n]
+    for i in (0, 17, 400, 1999):
+        row = g['boards'][i].astype(np.int32)
+        assert agent.evaluate(row) == g[f'value{n}'][i]
+        assert np.array_equal(agent.features(row), golden('features.npz')[f'f{n}'][i])
+    # the estimator protocol of Game._find_best_move (game_logic.py:150-161)
+    game = api.Game(row=g['sel_boards'][5].astype(np.int32))
+    best_dir, best_row, best_score = game._find_best_move(agent.evaluate, 0, 1, 0)
+    assert best_dir == g[f'action{n}'][5]
+    ref = w.astype(np.float64)
+    agent.update(g['up_states'][3].astype(np.int32), 0.125)
+    rb.update(n, ref, g['up_states'][3:4], [0.125])
+    got = np.concatenate([np.asarray(r) for r in agent.weights]).astype(np.float64)
+    assert np.abs(got - ref).max() < 1e-6
+    groups = agent.list_to_np()
+    assert [a.shape[0] for a in groups] == list(agent.weight_signature) and groups[0].dtype == np.float32
+
+
+def test_agent_episode_returns_a_replayable_game(api):
+    agent = api.QAgent(name='t', storage='local', console='local', n=3, alpha=0.2, seed=5)
+    before = np.concatenate([np.asarray(r) for r in agent.weights])
+    game = agent.episode()
+    assert agent.step == 1 and game.moves[-1] == -1
+    assert game.odometer == len(game.moves) - 1 == len(game.tiles) > 20
+    assert game.game_over(game.row)
+    chain = game.replay(verbose=False)                         # moves + tiles reproduce the final board and score
+    assert np.array_equal(chain[game.odometer][0], game.row) and chain[game.odometer][1] == game.score
+    assert np.array_equal(chain[0][0], game.starting_position)
+    after = np.concatenate([np.asarray(r) for r in agent.weights])
+    assert np.abs(after - before).max() > 0                    # it learned something
+
+
+def test_agent_pickle_round_trip(api, tmp_path):
+    agent = api.QAgent(name=str(tmp_path / 'agent_a'), storage='local', console='local', n=2, alpha=0.1)
+    agent.step, agent.top_score = 12, 345
+    w = np.concatenate([np.asarray(r) for r in agent.weights])
+    agent.save_agent()
+    loaded = api.QAgent.load_agent_local(agent.file)
+    assert (loaded.n, loaded.alpha, loaded.step, loaded.top_score, loaded.weight_signature) == (2, 0.1, 12, 345, (24,))
+    assert np.array_equal(np.concatenate([np.asarray(r) for r in loaded.weights]), w)
+    blob = pickle.dumps(agent)
+    assert b'game2048.r_learning' in blob                       # the class path the reference's pickles use
+
+
+def test_trial_runs_greedy_games_on_the_device(api):
+    agent = api.QAgent(name='t', storage='local', console='local', n=2, seed=9)
+    lines = []
+    import builtins
+    real_print = builtins.print
+    builtins.print = lambda *a, **k: lines.append(' '.join(str(x) for x in a))
+    try:
+        results = api.QAgent.trial(estimator=agent.evaluate, num=64, storage='local', console='local')
+    finally:
+        builtins.print = real_print
+    assert len(results) == 64 and all(g.game_over(g.row) for g in results[:8])
+    assert results[0].score >= results[-1].score and all(g.odometer > 10 for g in results)
+    assert any('average score of 64 runs' in ln for ln in lines) and any('2048 reached in' in ln for ln in lines)
+
+
+def test_batched_training_learns(api):
+    """Learning sanity (BASELINE.md quality rows are per 20 000+ episodes of the reference; here: the mean score of
+    finished games must rise clearly within a few game generations of 4096 concurrent episodes, n = 4)."""
+    agent = api.QAgent(name='t', storage='local', console='local', n=4, alpha=0.25, batch=4096, seed=11)
+    logs = []
+    agent.print = logs.append
+    agent.train_run(num_eps=60000, saving=False)
+    hist = agent.train_history
+    assert agent.step >= 60000 and len(hist) >= 10
+    early, late = np.mean(hist[:3]), np.mean(hist[-3:])
+    assert late > 2.0 * early, (early, late)
+    assert any('average over last 1000 episodes' in str(ln) for ln in logs)

@@ -14,8 +14,11 @@ import csv, sys, collections
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 with open(sys.argv[1]) as f:
     for row in csv.DictReader(f):
-        k = row['Kernel_Name'].split('(')[0][-40:]
+        import re
+        m = re.search(r'(k_[a-z_]+(<\d+(, *\d+)?>)?)', row['Kernel_Name'])
+        k = m.group(1) if m else row['Kernel_Name'][:40]
         agg[k][row['Counter_Name']].append(float(row['Counter_Value']))
-for k, d in agg.items():
-    print(k, {c: (len(v), sum(v) / len(v)) for c, v in d.items()})
+import json
+out = {k: {c: {'launches': len(v), 'mean': sum(v) / len(v)} for c, v in d.items()} for k, d in agg.items()}
+print(json.dumps(out, indent=1))
 PY
