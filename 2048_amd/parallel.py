@@ -55,7 +55,12 @@ class DeltaSync:
     def all_reduce(self):
         """D = W - W0 on every rank; D <- sum over ranks; W = W0 + D; W0 = W (the next epoch starts here)."""
         self.table.delta_extract_into(self.buf)            # synchronises the engine's stream
-        self.dist.all_reduce(self.buf, op=self.dist.ReduceOp.SUM, group=self.group)
+        if self.buf.is_cuda and self.dist.get_backend(self.group) == 'gloo':
+            host = self.buf.cpu()                          # rehearsal on a box without RCCL peers: stage through the host
+            self.dist.all_reduce(host, op=self.dist.ReduceOp.SUM, group=self.group)
+            self.buf.copy_(host)
+        else:
+            self.dist.all_reduce(self.buf, op=self.dist.ReduceOp.SUM, group=self.group)
         if self.buf.is_cuda:
             self.torch.cuda.synchronize(self.buf.device)
         self.table.delta_apply_from(self.buf)

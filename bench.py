@@ -70,6 +70,7 @@ def main():
     ap.add_argument('--epoch', type=int, default=50, help='steps between weight-delta all-reduces (N > 1)')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse on one GPU)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -83,8 +84,13 @@ def main():
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))   # RCCL over xGMI
+        if args.backend == 'nccl':
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))   # RCCL over xGMI
+        else:
+            local_rank = local_rank % torch.cuda.device_count()
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(args.backend)
 
     pkg = importlib.import_module('2048_amd')
     par = importlib.import_module('2048_amd.parallel')
@@ -123,7 +129,7 @@ def main():
     dt = time.perf_counter() - t0
     if dist:
         import torch
-        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        t = torch.tensor([dt], dtype=torch.float64, device='cuda' if args.backend == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
