@@ -492,6 +492,11 @@ struct Slice {
     uint32_t dlo;           // where the slice is added at flush time: index into the orbit table D (n >= 4) or into w (n = 2, 3)
     uint32_t part, nparts;  // records [count * part / nparts, count * (part + 1) / nparts)
     uint32_t chunk;         // hit counter of this slice (load statistics for the planner)
+    uint32_t fold;          // fold same-slot lanes of a wave before the LDS add (lds_add_folded)
+    // Chunks of the same orbit table that nobody holds in LDS (they see too few adds to be worth a record scan) are
+    // added straight into D with global atomics by the orbit's busiest chunk: bit k of fb_mask = chunk k of the orbit
+    // is this workgroup's duty.  orb_tlo / orb_dlo / chunk0: first table slot, first D index, first hit counter of the orbit.
+    uint32_t fb_mask, orb_tlo, orb_dlo, chunk0;
 };
 
 // Symmetry orbits (n >= 4).  QAgent.update adds dw at f_i(g.x) for all 8 images g (r_learning.py:207-214).  Features
@@ -563,7 +568,8 @@ __device__ __forceinline__ void lds_add_folded(float* acc, uint32_t local, float
 }
 
 template <int N, int F0, int FC>
-__device__ __forceinline__ void own_accum(const Packed& p, float dw, bool valid, float* acc, const Slice& sl, uint32_t& nhit) {
+__device__ __forceinline__ void own_accum(const Packed& p, float dw, bool valid, float* acc, const Slice& sl, uint32_t& nhit, float* D,
+                                          uint32_t* fb_hits) {
     constexpr int F = Shape<N>::F;
 #pragma unroll
     for (uint32_t g = 0; g < 8; ++g) {
@@ -573,14 +579,24 @@ __device__ __forceinline__ void own_accum(const Packed& p, float dw, bool valid,
         for (int f = F0; f < F0 + FC; ++f) {
             const uint32_t local = s[f] - sl.tlo;
             const bool hit = valid && local < sl.size;
-            lds_add_folded(acc, local, dw, hit);
+            if (sl.fold)
+                lds_add_folded(acc, local, dw, hit);
+            else if (hit)
+                atomicAdd(&acc[local], dw);
             nhit += hit ? 1u : 0u;
+            if (N >= 4 && sl.fb_mask && valid && !hit) {
+                const uint32_t rel = s[f] - sl.orb_tlo, ch = rel / OWN_SLOTS;
+                if ((sl.fb_mask >> ch) & 1u) {
+                    __hip_atomic_fetch_add(&D[sl.orb_dlo + rel], dw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    atomicAdd(&fb_hits[ch], 1u);            // LDS counter, flushed once per workgroup
+                }
+            }
         }
     }
 }
 
 template <int N, int V>
-__device__ __forceinline__ void own_run(float* acc, const Slice& s, const TdRecs& recs, uint32_t B, uint32_t* hits) {
+__device__ __forceinline__ void own_run(float* acc, const Slice& s, const TdRecs& recs, uint32_t B, uint32_t* hits, float* D, uint32_t* fb_hits) {
     constexpr int F0 = OwnVariants<N>::f0(V), FC = OwnVariants<N>::fc(V), OWN_UNROLL = OwnUnroll<FC>::U;
     uint32_t nhit = 0;
     {   // main records: this part's share of the lanes, OWN_UNROLL records per thread in flight; the loop bounds are
@@ -598,7 +614,7 @@ __device__ __forceinline__ void own_run(float* acc, const Slice& s, const TdRecs
                 dw[u] = ok ? recs.dw1[rr] : 0.0f;
             }
 #pragma unroll
-            for (int u = 0; u < OWN_UNROLL; ++u) own_accum<N, F0, FC>(unpack4(st[u]), dw[u], dw[u] != 0.0f, acc, s, nhit);
+            for (int u = 0; u < OWN_UNROLL; ++u) own_accum<N, F0, FC>(unpack4(st[u]), dw[u], dw[u] != 0.0f, acc, s, nhit, D, fb_hits);
         }
     }
     {   // terminal queue
@@ -608,7 +624,7 @@ __device__ __forceinline__ void own_run(float* acc, const Slice& s, const TdRecs
             const uint32_t r = base0 + threadIdx.x;
             const bool ok = r < end;
             const uint32_t rr = ok ? r : end - 1;
-            own_accum<N, F0, FC>(ld_packed(recs.qstate, rr), recs.qdw[rr], ok, acc, s, nhit);
+            own_accum<N, F0, FC>(ld_packed(recs.qstate, rr), recs.qdw[rr], ok, acc, s, nhit, D, fb_hits);
         }
     }
     // load statistics for the planner: one counter bump per wave
@@ -618,12 +634,13 @@ __device__ __forceinline__ void own_run(float* acc, const Slice& s, const TdRecs
 }
 
 template <int N, int V>
-__device__ __forceinline__ void own_dispatch(float* acc, const Slice& s, const TdRecs& recs, uint32_t B, uint32_t* hits) {
+__device__ __forceinline__ void own_dispatch(float* acc, const Slice& s, const TdRecs& recs, uint32_t B, uint32_t* hits, float* D,
+                                             uint32_t* fb_hits) {
     if constexpr (V < OwnVariants<N>::COUNT) {
         if (s.variant == (uint32_t)V)
-            own_run<N, V>(acc, s, recs, B, hits);
+            own_run<N, V>(acc, s, recs, B, hits, D, fb_hits);
         else
-            own_dispatch<N, V + 1>(acc, s, recs, B, hits);
+            own_dispatch<N, V + 1>(acc, s, recs, B, hits, D, fb_hits);
     }
 }
 
@@ -631,11 +648,14 @@ __device__ __forceinline__ void own_dispatch(float* acc, const Slice& s, const T
 template <int N>
 __global__ __launch_bounds__(OWN_WG) void k_td_update_owner(float* dst, TdRecs recs, uint32_t B, const Slice* slices, uint32_t* hits) {
     __shared__ float acc[OWN_SLOTS];
+    __shared__ uint32_t fb_hits[32];
     const Slice s = slices[blockIdx.x];
     for (uint32_t j = threadIdx.x; j < s.size; j += OWN_WG) acc[j] = 0.0f;
+    if (threadIdx.x < 32) fb_hits[threadIdx.x] = 0;
     __syncthreads();
-    own_dispatch<N, 0>(acc, s, recs, B, hits);
+    own_dispatch<N, 0>(acc, s, recs, B, hits, dst, fb_hits);
     __syncthreads();
+    if (threadIdx.x < 32 && fb_hits[threadIdx.x]) atomicAdd(&hits[s.chunk0 + threadIdx.x], fb_hits[threadIdx.x]);
     if (s.nparts == 1) {
         for (uint32_t j = threadIdx.x; j < s.size; j += OWN_WG) {
             float v = acc[j];
@@ -748,7 +768,7 @@ struct g2048_ctx {
     uint32_t n_slices = 0;
     uint32_t* hits = nullptr;           // adds per table chunk since the last re-plan (load statistics)
     uint32_t n_chunks = 0;
-    uint32_t steps_since_plan = 0, replan_every = 8;
+    uint32_t steps_since_plan = 0, replan_every = 8;     // the board distribution drifts with the games' age: follow it closely
     std::vector<double> load;           // smoothed adds per step per chunk
     float* D = nullptr;                 // per-orbit delta tables (n >= 4)
     OrbitTable orbits = {};
@@ -928,21 +948,24 @@ constexpr uint32_t WG_BUDGET = 250;
 struct ChunkInfo {
     uint32_t variant, tlo, size, dlo;
     double scan;        // relative cost of scanning one record for this chunk
+    uint32_t orb_tlo, orb_dlo, chunk0, orb_chunks;      // the orbit table this chunk belongs to (n >= 4)
 };
 
 std::vector<ChunkInfo> table_chunks(const g2048_ctx* c) {
     std::vector<ChunkInfo> v;
     if (c->n == 2) {
-        v.push_back({0, 0, Shape<2>::SLOTS, 0, 6.0});
+        v.push_back({0, 0, Shape<2>::SLOTS, 0, 6.0, 0, 0, 0, 1});
     } else if (c->n == 3) {
-        for (uint32_t g = 0; g < 7; ++g) v.push_back({g, g * 8u * 4096u, (g < 6 ? 8u : 4u) * 4096u, g * 8u * 4096u, 3.0});
+        for (uint32_t g = 0; g < 7; ++g) v.push_back({g, g * 8u * 4096u, (g < 6 ? 8u : 4u) * 4096u, g * 8u * 4096u, 3.0, 0, 0, g, 1});
     } else if (c->n >= 4) {
         for (uint32_t o = 0; o < c->orbits.count; ++o) {
             const OrbitInfo& oi = c->orbits.o[o];
             uint32_t rep = 0;
             for (int j = 0; j < 21 && j < c->F; ++j)
                 if (feature_offset(c->n, j) == oi.off[0]) rep = (uint32_t)j;
-            for (uint32_t lo = 0; lo < oi.size; lo += OWN_SLOTS) v.push_back({rep, oi.off[0] + lo, OWN_SLOTS, oi.base + lo, oi.nibbles == 4 ? 1.0 : 2.0});
+            const uint32_t first = (uint32_t)v.size();
+            for (uint32_t lo = 0; lo < oi.size; lo += OWN_SLOTS)
+                v.push_back({rep, oi.off[0] + lo, OWN_SLOTS, oi.base + lo, oi.nibbles == 4 ? 1.0 : 2.0, oi.off[0], oi.base, first, oi.size / OWN_SLOTS});
         }
     }
     return v;
@@ -982,21 +1005,50 @@ int build_slices(g2048_ctx* c) {
             c->load[k] = 8.0 * c->B * share * (c->n == 2 ? 24 : c->n == 3 ? (chunks[k].size / 4096.0) : 1);
         }
     }
-    double add_cost = 1.5;
+    double add_cost = 1.5, thr = 0.01;
     if (const char* e = getenv("G2048_PLAN_ADDCOST")) add_cost = atof(e);      // (experiments)
+    if (const char* e = getenv("G2048_PLAN_THR")) thr = atof(e);
     const double B = c->B;
-    std::vector<double> cost(nc);
+    // which chunks get LDS workgroups: those with at least `thr` of their orbit's adds, and each orbit's busiest
+    std::vector<char> in_lds(nc, 1);
+    std::vector<uint32_t> duty(nc, 0);      // fallback mask carried by a chunk
+    if (c->n >= 4 && c->B >= 4096)
+        for (size_t k0 = 0; k0 < nc; k0 += chunks[k0].orb_chunks) {
+            const size_t cnt = chunks[k0].orb_chunks;
+            double orbit_total = 0;
+            size_t best = k0;
+            for (size_t j = k0; j < k0 + cnt; ++j) {
+                orbit_total += c->load[j];
+                if (c->load[j] > c->load[best]) best = j;
+            }
+            for (size_t j = k0; j < k0 + cnt; ++j)
+                if (j != best && c->load[j] < thr * orbit_total) {
+                    in_lds[j] = 0;
+                    duty[best] |= 1u << (j - k0);
+                }
+        }
+    std::vector<double> cost(nc, 0.0);
     double total = 0;
-    for (size_t k = 0; k < nc; ++k) {
-        cost[k] = chunks[k].scan * B + add_cost * c->load[k];
-        total += cost[k];
-    }
-    const uint32_t budget = c->B < (1u << 14) ? (uint32_t)nc : (WG_BUDGET > nc ? WG_BUDGET : (uint32_t)nc);
+    size_t n_lds = 0;
+    for (size_t k = 0; k < nc; ++k)
+        if (in_lds[k]) {
+            cost[k] = chunks[k].scan * B + add_cost * c->load[k];
+            total += cost[k];
+            ++n_lds;
+        }
+    const uint32_t budget = c->B < (1u << 14) ? (uint32_t)n_lds : (WG_BUDGET > n_lds ? WG_BUDGET : (uint32_t)n_lds);
+    // Folding same-slot lanes before the LDS add costs ~0.3 ms per step in steady state and saves ~0.1 ms in the worst
+    // phase (all games young and in step): off unless asked for (measured: DESIGN.md section 4).
+    uint32_t fold = 0;
+    if (const char* e = getenv("G2048_FOLD")) fold = (uint32_t)atoi(e);
     std::vector<Slice> v;
-    std::vector<uint32_t> parts(nc);
+    std::vector<uint32_t> parts(nc, 0);
     for (size_t k = 0; k < nc; ++k) {
-        parts[k] = 1 + (uint32_t)((budget - nc) * cost[k] / total);
-        for (uint32_t p = 0; p < parts[k]; ++p) v.push_back(Slice{chunks[k].variant, chunks[k].tlo, chunks[k].size, chunks[k].dlo, p, parts[k], (uint32_t)k});
+        if (!in_lds[k]) continue;
+        parts[k] = 1 + (uint32_t)((budget - n_lds) * cost[k] / total);
+        for (uint32_t p = 0; p < parts[k]; ++p)
+            v.push_back(Slice{chunks[k].variant, chunks[k].tlo, chunks[k].size, chunks[k].dlo, p, parts[k], (uint32_t)k, fold, duty[k],
+                              chunks[k].orb_tlo, chunks[k].orb_dlo, chunks[k].chunk0});
     }
     if (v.size() > MAX_SLICES) return fail(c, G2048_ERR_STATE, "LDS-owner plan too large");
     // longest-running workgroups first
@@ -1020,7 +1072,6 @@ int replan(g2048_ctx* c) {
     if (int rc = d2h(c, h.data(), c->hits, h.size() * 4)) return rc;
     HIP_TRY(c, hipMemsetAsync(c->hits, 0, h.size() * 4, c->stream));
     for (size_t k = 0; k < h.size(); ++k) c->load[k] = 0.5 * c->load[k] + 0.5 * (double)h[k] / c->steps_since_plan;
-    c->replan_every = c->replan_every < 64 ? c->replan_every * 2 : 64;
     return build_slices(c);
 }
 
