@@ -66,24 +66,50 @@ struct Stats {   // device mirror of g2048_stats (all u64)
 };
 static_assert(sizeof(Stats) == sizeof(g2048_stats), "stats layout");
 
-__device__ __forceinline__ void count_finished(Stats* st, const Board& b, int32_t score, bool overflow) {
-    atomicAdd(&st->episodes, 1ull);
-    atomicAdd(&st->score_sum, (unsigned long long)(score < 0 ? 0 : score));
-    atomicMax(&st->best_score, (unsigned long long)(score < 0 ? 0 : score));
-    uint32_t t = max_tile(b);
-    atomicAdd(&st->max_tile[t > 19u ? 19u : t], 1ull);
-    if (overflow) atomicAdd(&st->overflow16, 1ull);
+// Episode statistics are accumulated per workgroup in LDS and flushed with one global atomic per non-zero counter:
+// thousands of lanes finishing in the same step would otherwise all hit the same few addresses (same-address global
+// atomics run at well under 1 G/s).
+struct WgStats {
+    unsigned long long score_sum;
+    unsigned int episodes, moves, best, overflow16, max_tile[20];
+};
+
+__device__ __forceinline__ void wg_stats_init(WgStats* ws) {
+    if (threadIdx.x < 20) ws->max_tile[threadIdx.x] = 0;
+    if (threadIdx.x == 0) {
+        ws->score_sum = 0;
+        ws->episodes = ws->moves = ws->best = ws->overflow16 = 0;
+    }
+    __syncthreads();
 }
 
-// one atomic per workgroup for the number of board-steps executed
-__device__ __forceinline__ void count_moves(Stats* st, bool moved) {
-    __shared__ unsigned int wg_moves;
-    if (threadIdx.x == 0) wg_moves = 0;
+__device__ __forceinline__ void count_finished(WgStats* ws, const Board& b, int32_t score, bool overflow) {
+    const unsigned int sc = score < 0 ? 0u : (unsigned int)score;
+    atomicAdd(&ws->episodes, 1u);
+    atomicAdd(&ws->score_sum, (unsigned long long)sc);
+    atomicMax(&ws->best, sc);
+    uint32_t t = max_tile(b);
+    atomicAdd(&ws->max_tile[t > 19u ? 19u : t], 1u);
+    if (overflow) atomicAdd(&ws->overflow16, 1u);
+}
+
+// board-steps executed: one LDS add per wave
+__device__ __forceinline__ void count_moves(WgStats* ws, unsigned int my_moves) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) my_moves += __shfl_down(my_moves, off);
+    if ((threadIdx.x & 63) == 0 && my_moves) atomicAdd(&ws->moves, my_moves);
+}
+
+__device__ __forceinline__ void wg_stats_flush(const WgStats* ws, Stats* st) {
     __syncthreads();
-    unsigned long long m = __ballot(moved);
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&wg_moves, (unsigned int)__popcll(m));
-    __syncthreads();
-    if (threadIdx.x == 0 && wg_moves) atomicAdd(&st->moves, (unsigned long long)wg_moves);
+    if (threadIdx.x < 20 && ws->max_tile[threadIdx.x]) atomicAdd(&st->max_tile[threadIdx.x], (unsigned long long)ws->max_tile[threadIdx.x]);
+    if (threadIdx.x == 32) {
+        if (ws->episodes) atomicAdd(&st->episodes, (unsigned long long)ws->episodes);
+        if (ws->moves) atomicAdd(&st->moves, (unsigned long long)ws->moves);
+        if (ws->score_sum) atomicAdd(&st->score_sum, ws->score_sum);
+        if (ws->best) atomicMax(&st->best_score, (unsigned long long)ws->best);
+        if (ws->overflow16) atomicAdd(&st->overflow16, (unsigned long long)ws->overflow16);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ lane state
@@ -208,6 +234,8 @@ __global__ __launch_bounds__(WG) void k_spawn(uint4* boards, ulonglong2* rng, ui
 // with the lane state held in registers for the whole launch.
 __global__ __launch_bounds__(WG) void k_step_random(uint4* boards, int32_t* scores, ulonglong2* rng, uint8_t* flags, uint32_t B,
                                                     uint32_t nsteps, int auto_reset, Stats* stats) {
+    __shared__ WgStats ws;
+    wg_stats_init(&ws);
     uint32_t i = blockIdx.x * WG + threadIdx.x;
     const bool in = i < B;
     Board b = {{0, 0, 0, 0}};
@@ -239,7 +267,7 @@ __global__ __launch_bounds__(WG) void k_step_random(uint4* boards, int32_t* scor
             over = true;                                        // a dead board was loaded
         }
         if (over) {
-            count_finished(stats, b, score, max_tile(b) >= 16u);
+            count_finished(&ws, b, score, max_tile(b) >= 16u);
             if (auto_reset) {
                 b = new_game(g);
                 score = 0;
@@ -248,11 +276,8 @@ __global__ __launch_bounds__(WG) void k_step_random(uint4* boards, int32_t* scor
             }
         }
     }
-    // one moves counter update per wave
-    unsigned int w = my_moves;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) w += __shfl_down(w, off);
-    if ((threadIdx.x & 63) == 0 && w) atomicAdd(&stats->moves, (unsigned long long)w);
+    count_moves(&ws, my_moves);
+    wg_stats_flush(&ws, stats);
     if (in) {
         st_board(boards, i, b);
         st_rng(rng, i, g);
@@ -393,6 +418,8 @@ __global__ __launch_bounds__(WG) void k_td_play(uint4* boards, int32_t* scores, 
                                                 uint32_t B, const float* __restrict__ w, float alpha, TdRecs recs, int auto_reset,
                                                 Stats* stats, uint16_t* last_move) {
     constexpr float F = (float)Shape<N>::F;
+    __shared__ WgStats ws;
+    wg_stats_init(&ws);
     uint32_t i = blockIdx.x * WG + threadIdx.x;
     if (i == 0) *recs.qcount_next = 0;
     bool moved = false;
@@ -441,7 +468,7 @@ __global__ __launch_bounds__(WG) void k_td_play(uint4* boards, int32_t* scores, 
             }
             if (over) {
                 lm |= 1u << 11;
-                count_finished(stats, b, score, overflow);
+                count_finished(&ws, b, score, overflow);
                 if (auto_reset) {
                     b = new_game(g);
                     score = 0;
@@ -460,7 +487,8 @@ __global__ __launch_bounds__(WG) void k_td_play(uint4* boards, int32_t* scores, 
         recs.dw1[i] = dw1;
         last_move[i] = (uint16_t)lm;
     }
-    count_moves(stats, moved);
+    count_moves(&ws, moved ? 1u : 0u);
+    wg_stats_flush(&ws, stats);
 }
 
 // Step part 2, global-atomics form — QAgent.update for every record: thread t adds image (t & 7) of record (t >> 3);
@@ -1457,7 +1485,7 @@ int g2048_evaluate(g2048_ctx* c, float* value) {
 }
 
 int g2048_eval_select(g2048_ctx* c, float* value, uint8_t* action, float* values4) {
-    if (!c || !value || !action) return c ? fail(c, G2048_ERR_ARG, "null buffer") : G2048_ERR_ARG;
+    if (!c || ((value == nullptr) != (action == nullptr))) return c ? fail(c, G2048_ERR_ARG, "null buffer") : G2048_ERR_ARG;
     NEED_TABLE(c);
     if (int rc = bind(c)) return rc;
     const size_t B = c->B;
@@ -1467,6 +1495,7 @@ int g2048_eval_select(g2048_ctx* c, float* value, uint8_t* action, float* values
     uint8_t* d_a = (uint8_t*)c->scratch + B * 20;
     BY_N(c, (k_eval_select<N><<<grid_for(B), WG, 0, c->stream>>>(c->boards, c->B, c->w, d_v, d_a, values4 ? d_v4 : nullptr)));
     if (int rc = launched(c, "k_eval_select")) return rc;
+    if (!value) return G2048_OK;            // device-only run (results stay in the context's scratch buffer; benchmarking)
     int rc;
     if ((rc = d2h(c, value, d_v, B * 4)) || (rc = d2h(c, action, d_a, B))) return rc;
     if (values4 && (rc = d2h(c, values4, d_v4, B * 16))) return rc;

@@ -168,6 +168,10 @@ class Engine:
         self._c(self.lib.g2048_eval_select(self.ctx, _buf(v), _buf(a), _buf(v4) if want_all else None))
         return (v, a, v4) if want_all else (v, a)
 
+    def eval_select_device_only(self):
+        """Run the greedy-choice kernel without copying anything back (timing)."""
+        self._c(self.lib.g2048_eval_select(self.ctx, None, None, None))
+
     # ---- learning
     def update(self, states, dw):
         s = np.ascontiguousarray(np.asarray(states).reshape(-1, 16), np.uint8)

@@ -59,6 +59,40 @@ def cpu_baseline(n, seconds):
                        f'(oracle/ref_scalar.py, NumPy {np.__version__}, host has {os.cpu_count()} logical cores)')
 
 
+def side_workload(pkg, args):
+    """BASELINE configs 2 and 3 (parity-test cases, measured for DESIGN.md; not the bench metric)."""
+    if args.workload == 'env':
+        B = 65536 if args.batch == 1 << 20 else args.batch
+        eng = pkg.Engine(B, n=0, seed=2048)
+        eng.step_random(args.warmup)
+        eng.sync()
+        eng.timer_start()
+        eng.step_random(args.steps)                # one launch, lane state in registers for all `steps`
+        ms = eng.timer_stop()
+        out = dict(workload='BASELINE config 2: env step only, random valid direction', batch=B, steps=args.steps,
+                   value=B * args.steps / (ms * 1e-3), unit='board-steps/s', ms_per_step=ms / args.steps,
+                   algorithmic_GBps=72 * B * args.steps / (ms * 1e-3) / 1e9)
+    else:
+        B = 262144 if args.batch == 1 << 20 else args.batch
+        n = 3 if args.n_tuple == 5 else args.n_tuple
+        eng = pkg.Engine(B, n=n, seed=2048)
+        eng.step_random(64)
+        eng.init_weights(seed=7, scale=0.01)
+        for _ in range(args.warmup):
+            eng.eval_select_device_only()
+        eng.sync()
+        eng.timer_start()
+        for _ in range(args.steps):
+            eng.eval_select_device_only()
+        ms = eng.timer_stop()
+        by = 16 + 4 * NUM_FEAT[n] * 4 + 5
+        out = dict(workload=f'BASELINE config 3: {n}-tuple evaluate + 4-way greedy select, inference only', batch=B,
+                   steps=args.steps, value=B * args.steps / (ms * 1e-3), unit='boards/s', ms_per_step=ms / args.steps,
+                   algorithmic_GBps=by * B * args.steps / (ms * 1e-3) / 1e9)
+    print(json.dumps(out), flush=True)
+    eng.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -70,6 +104,9 @@ def main():
     ap.add_argument('--epoch', type=int, default=50, help='steps between weight-delta all-reduces (N > 1)')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--workload', default='td', choices=['td', 'env', 'eval'],
+                    help='td = BASELINE config 4 (the metric); env = config 2 (65 536 lanes, env step only); eval = config 3 '
+                         '(262 144 lanes, n=3 evaluate + greedy select); env/eval print a reduced JSON line')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse on one GPU)')
     args = ap.parse_args()
 
@@ -94,6 +131,8 @@ def main():
 
     pkg = importlib.import_module('2048_amd')
     par = importlib.import_module('2048_amd.parallel')
+    if args.workload != 'td':
+        return side_workload(pkg, args)
     eng = pkg.Engine(B, n=n, seed=2048, lane0=rank * B, device=local_rank)
     eng.init_weights(seed=7, scale=0.01)                   # same table on every rank (counter-based init)
     # batch rule: every lane adds its delta in the same step and one slot can be hit by all 8 images of every

@@ -105,7 +105,7 @@ int g2048_weights_init(g2048_ctx* ctx, uint64_t seed, float scale);       /* U[0
 int g2048_evaluate(g2048_ctx* ctx, float* value /* [B] */);               /* QAgent.evaluate, r_learning.py:202-203 */
 /* greedy afterstate choice (r_learning.py:229-237, game_logic.py:150-161 at depth 0): first maximum over the
  * directions that change the board; action 255 / value 0 when none does.  values4 ([B][4], may be NULL) gets
- * V(afterstate d) or -inf. */
+ * V(afterstate d) or -inf.  value and action may both be NULL: the kernel runs and nothing is copied back. */
 int g2048_eval_select(g2048_ctx* ctx, float* value /* [B] */, uint8_t* action /* [B] */, float* values4);
 
 /* ---- learning */
