@@ -533,22 +533,37 @@ struct Slice {
 //     f_i(x) = perm_i(f_rep(h_i . x))  for all x   =>   delta_table_i[perm_i(k)] = D_rep[k].
 // So the owner kernel accumulates one table D per orbit (6 orbits instead of 21 features: 3.5x fewer index
 // computations, LDS adds and record scans) and k_apply_orbits adds D into every member table through its permutation.
-constexpr int MAX_ORBITS = 8, MAX_MEMBERS = 4;
+constexpr int MAX_ORBITS = 8, MAX_MEMBERS = 8;
 struct OrbitInfo {
     uint32_t base, size;                // D[base .. base + size)
     uint32_t nmem;
     uint32_t off[MAX_MEMBERS];          // first table slot of each member feature
-    uint32_t perm[MAX_MEMBERS];         // 3 bits per output nibble p: the input nibble it takes (out nibble p = in nibble src[p])
-    uint32_t nibbles;                   // 4 or 5
+    uint32_t perm[MAX_MEMBERS];         // 3 bits per output digit p: the input digit it takes (out digit p = in digit src[p])
+    uint32_t digits, radix;             // 4 or 5 digits in base 16 (nibbles), or 6 digits in base 14 (the f_6 features)
 };
 struct OrbitTable {
     uint32_t count, total;
     OrbitInfo o[MAX_ORBITS];
 };
 
-G2048_HD uint32_t permute_nibbles(uint32_t k, uint32_t perm, uint32_t nibbles) {
-    uint32_t out = 0;
-    for (uint32_t p = 0; p < nibbles; ++p) out |= ((k >> (4u * ((perm >> (3u * p)) & 7u))) & 15u) << (4u * p);
+G2048_HD uint32_t permute_digits(uint32_t k, uint32_t perm, uint32_t digits, uint32_t radix) {
+    if (radix == 16u) {
+        uint32_t out = 0;
+        for (uint32_t p = 0; p < digits; ++p) out |= ((k >> (4u * ((perm >> (3u * p)) & 7u))) & 15u) << (4u * p);
+        return out;
+    }
+    uint32_t d[6], out = 0, mul = 1;
+    for (uint32_t p = 0; p < 6u; ++p) {
+        d[p] = k % 14u;
+        k /= 14u;
+    }
+    for (uint32_t p = 0; p < 6u; ++p) {
+        const uint32_t src = (perm >> (3u * p)) & 7u;
+        uint32_t v = d[0];                      // select without dynamic indexing
+        v = src == 1u ? d[1] : v; v = src == 2u ? d[2] : v; v = src == 3u ? d[3] : v; v = src == 4u ? d[4] : v; v = src == 5u ? d[5] : v;
+        out += v * mul;
+        mul *= 14u;
+    }
     return out;
 }
 
@@ -711,31 +726,57 @@ __global__ __launch_bounds__(WG) void k_apply_orbits(float* w, float* D, OrbitTa
         if (j < t.count && K >= t.o[j].base) o = j;
     const OrbitInfo& oi = t.o[o];
     const uint32_t k = K - oi.base;
-    for (uint32_t m = 0; m < oi.nmem; ++m) w[oi.off[m] + permute_nibbles(k, oi.perm[m], oi.nibbles)] += v;
+    for (uint32_t m = 0; m < oi.nmem; ++m) w[oi.off[m] + permute_digits(k, oi.perm[m], oi.digits, oi.radix)] += v;
 }
 
-// n = 6: the twelve 14^6-slot tables (361 MB) do not fit in LDS; their 96 adds per record stay global atomics
-template <int N, int F0>
-__global__ __launch_bounds__(WG) void k_td_update_tail(float* w, TdRecs recs, uint32_t B) {
+// n = 6: the twelve 14^6-slot tables (361 MB) do not fit in LDS, so their adds end as global atomics — but (1) through
+// the orbits: the 12 features fall into two orbits (8 corner blocks, 4 middle blocks) whose representatives are
+// features 21 and 22, so a record costs 2 x 8 = 16 adds into D instead of 96 into the table; and (2) through a
+// per-workgroup combining cache in LDS: memory-side atomics serialise per address (a slot that takes 5 % of a step's
+// adds costs milliseconds), so every workgroup first sums its adds in a 16 384-entry direct-mapped {slot, sum} cache
+// and only cache misses and the final flush touch HBM.
+constexpr uint32_t TAIL_CACHE = 16384, TAIL_EMPTY = 0xFFFFFFFFu;
+
+__device__ __forceinline__ void cached_add(uint32_t* keys, float* vals, float* D, uint32_t slot, float dw) {
+    const uint32_t h = (slot * 2654435761u) >> 18;                 // 14 bits
+    const uint32_t prev = atomicCAS(&keys[h], TAIL_EMPTY, slot);
+    if (prev == TAIL_EMPTY || prev == slot)
+        atomicAdd(&vals[h], dw);
+    else
+        __hip_atomic_fetch_add(&D[slot], dw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int N>
+__global__ __launch_bounds__(OWN_WG) void k_td_update_tail(float* D, TdRecs recs, uint32_t B, uint32_t dbaseA, uint32_t dbaseB) {
     constexpr int F = Shape<N>::F;
-    uint32_t t = blockIdx.x * WG + threadIdx.x;
-    uint32_t r = t >> 3, g = t & 7u;
-    Packed p;
-    float dw;
-    if (r < B) {
-        dw = recs.dw1[r];
-        if (dw == 0.0f) return;
-        p = ld_packed(recs.state1, r);
-    } else if (r - B < *recs.qcount) {
-        dw = recs.qdw[r - B];
-        p = ld_packed(recs.qstate, r - B);
-    } else {
-        return;
+    __shared__ uint32_t keys[TAIL_CACHE];
+    __shared__ float vals[TAIL_CACHE];
+    for (uint32_t j = threadIdx.x; j < TAIL_CACHE; j += OWN_WG) {
+        keys[j] = TAIL_EMPTY;
+        vals[j] = 0.0f;
     }
-    uint32_t s[F];
-    feature_slots<N>(d4_image(p, g), s);
-#pragma unroll
-    for (int f = F0; f < F; ++f) __hip_atomic_fetch_add(&w[s[f]], dw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const uint32_t total = (B + *recs.qcount) * 8u;                // (record, image) pairs; records >= B are the terminal queue
+    for (uint32_t t = blockIdx.x * OWN_WG + threadIdx.x; t < total; t += gridDim.x * OWN_WG) {
+        const uint32_t r = t >> 3, g = t & 7u;
+        Packed p;
+        float dw;
+        if (r < B) {
+            dw = recs.dw1[r];
+            if (dw == 0.0f) continue;
+            p = ld_packed(recs.state1, r);
+        } else {
+            dw = recs.qdw[r - B];
+            p = ld_packed(recs.qstate, r - B);
+        }
+        uint32_t s[F];
+        feature_slots<N>(d4_image(p, g), s);
+        cached_add(keys, vals, D, dbaseA + (s[21] - feature_offset(N, 21)), dw);
+        cached_add(keys, vals, D, dbaseB + (s[22] - feature_offset(N, 22)), dw);
+    }
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < TAIL_CACHE; j += OWN_WG)
+        if (keys[j] != TAIL_EMPTY && vals[j] != 0.0f) __hip_atomic_fetch_add(&D[keys[j]], vals[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // init_weights (r_learning.py:139-149): U[0, scale) per slot, counter-based so any rank can build the same table
@@ -903,49 +944,64 @@ uint32_t host_feature_index(const Packed& p, int f) {
 
 template <int N>
 int find_orbits(g2048_ctx* c) {
-    constexpr int NF = Shape<N>::F < 21 ? Shape<N>::F : 21;
+    constexpr int NF = Shape<N>::F;
+    constexpr int NB = 24;
     std::vector<Packed> boards;
     uint64_t x = 0x2048;
-    for (int t = 0; t < 24; ++t) {
+    for (int t = 0; t < NB; ++t) {
         Board b;
-        for (int r = 0; r < 4; ++r) {
-            uint64_t z = splitmix64(x);
-            b.r[r] = (uint32_t)(z & 0x0F0F0F0Fu);
-        }
+        for (int r = 0; r < 4; ++r) b.r[r] = (uint32_t)(splitmix64(x) & 0x0F0F0F0Fu) % 0x0E0E0E0Fu;   // tiles 0..13 (f_6 clamps at 13)
+        for (int r = 0; r < 4; ++r)
+            for (int col = 0; col < 4; ++col)
+                if (((b.r[r] >> (8 * col)) & 0xFFu) > 13u) b.r[r] &= ~(0xFFu << (8 * col));
         boards.push_back(pack_board(b));
     }
+    auto digits_of = [](uint32_t idx, uint32_t radix, uint32_t nd, uint32_t* out) {
+        for (uint32_t p = 0; p < nd; ++p) {
+            out[p] = idx % radix;
+            idx /= radix;
+        }
+    };
     OrbitTable& T = c->orbits;
     T.count = 0;
     T.total = 0;
+    std::vector<int> rep_of;
     for (int i = 0; i < NF; ++i) {
-        const uint32_t nib = i < 17 ? 4u : 5u;
+        const uint32_t nd = i < 17 ? 4u : (i < 21 ? 5u : 6u), radix = i < 21 ? 16u : 14u;
+        uint32_t mine[NB][6];
+        for (int t = 0; t < NB; ++t) digits_of(host_feature_index<N>(boards[t], i), radix, nd, mine[t]);
         bool placed = false;
         for (uint32_t o = 0; o < T.count && !placed; ++o) {
-            if (T.o[o].nibbles != nib) continue;
-            int rep = -1;       // the orbit's representative = its first member
-            for (int j = 0; j < NF; ++j)
-                if (feature_offset(N, j) == T.o[o].off[0]) rep = j;
-            std::vector<uint32_t> order(nib);
-            for (uint32_t q = 0; q < nib; ++q) order[q] = q;
-            do {
-                uint32_t perm = 0;
-                for (uint32_t q = 0; q < nib; ++q) perm |= order[q] << (3u * q);
-                for (uint32_t g = 0; g < 8 && !placed; ++g) {
-                    bool ok = true;
-                    for (const Packed& p : boards)
-                        if (host_feature_index<N>(p, i) != permute_nibbles(host_feature_index<N>(d4_image(p, g), rep), perm, nib)) {
-                            ok = false;
-                            break;
-                        }
-                    if (ok) {
-                        if (T.o[o].nmem >= MAX_MEMBERS) return fail(c, G2048_ERR_STATE, "orbit larger than expected");
-                        T.o[o].off[T.o[o].nmem] = feature_offset(N, i);
-                        T.o[o].perm[T.o[o].nmem] = perm;
-                        ++T.o[o].nmem;
-                        placed = true;
+            if (T.o[o].digits != nd || T.o[o].radix != radix) continue;
+            for (uint32_t g = 0; g < 8 && !placed; ++g) {
+                uint32_t theirs[NB][6];
+                for (int t = 0; t < NB; ++t) digits_of(host_feature_index<N>(d4_image(boards[t], g), rep_of[o]), radix, nd, theirs[t]);
+                // out digit p of feature i must equal some digit q of the representative on every board
+                uint32_t perm = 0, used = 0;
+                bool ok = true;
+                for (uint32_t pp = 0; pp < nd && ok; ++pp) {
+                    int found = -1;
+                    for (uint32_t q = 0; q < nd && found < 0; ++q) {
+                        if ((used >> q) & 1u) continue;
+                        bool same = true;
+                        for (int t = 0; t < NB && same; ++t) same = mine[t][pp] == theirs[t][q];
+                        if (same) found = (int)q;
+                    }
+                    if (found < 0) {
+                        ok = false;
+                    } else {
+                        used |= 1u << found;
+                        perm |= (uint32_t)found << (3u * pp);
                     }
                 }
-            } while (!placed && std::next_permutation(order.begin(), order.end()));
+                if (ok) {
+                    if (T.o[o].nmem >= MAX_MEMBERS) return fail(c, G2048_ERR_STATE, "orbit larger than expected");
+                    T.o[o].off[T.o[o].nmem] = feature_offset(N, i);
+                    T.o[o].perm[T.o[o].nmem] = perm;
+                    ++T.o[o].nmem;
+                    placed = true;
+                }
+            }
         }
         if (!placed) {
             if (T.count >= MAX_ORBITS) return fail(c, G2048_ERR_STATE, "more orbits than expected");
@@ -953,14 +1009,17 @@ int find_orbits(g2048_ctx* c) {
             oi = OrbitInfo{};
             oi.base = T.total;
             oi.size = feature_size(N, i);
-            oi.nibbles = nib;
+            oi.digits = nd;
+            oi.radix = radix;
             oi.nmem = 1;
             oi.off[0] = feature_offset(N, i);
-            uint32_t ident = 0;
-            for (uint32_t q = 0; q < nib; ++q) ident |= q << (3u * q);
-            oi.perm[0] = ident;
+            for (uint32_t q = 0; q < nd; ++q) oi.perm[0] |= q << (3u * q);
             T.total += oi.size;
+            rep_of.push_back(i);
         }
+    }
+    if (N == 6) {       // k_td_update_tail hard-codes the two f_6 representatives
+        if (T.count != 8 || rep_of[6] != 21 || rep_of[7] != 22) return fail(c, G2048_ERR_STATE, "unexpected f_6 orbit structure");
     }
     return G2048_OK;
 }
@@ -989,11 +1048,12 @@ std::vector<ChunkInfo> table_chunks(const g2048_ctx* c) {
         for (uint32_t o = 0; o < c->orbits.count; ++o) {
             const OrbitInfo& oi = c->orbits.o[o];
             uint32_t rep = 0;
+            if (oi.radix != 16u) continue;          // the f_6 orbits are not LDS-owned (k_td_update_tail)
             for (int j = 0; j < 21 && j < c->F; ++j)
                 if (feature_offset(c->n, j) == oi.off[0]) rep = (uint32_t)j;
             const uint32_t first = (uint32_t)v.size();
             for (uint32_t lo = 0; lo < oi.size; lo += OWN_SLOTS)
-                v.push_back({rep, oi.off[0] + lo, OWN_SLOTS, oi.base + lo, oi.nibbles == 4 ? 1.0 : 2.0, oi.off[0], oi.base, first, oi.size / OWN_SLOTS});
+                v.push_back({rep, oi.off[0] + lo, OWN_SLOTS, oi.base + lo, oi.digits == 4 ? 1.0 : 2.0, oi.off[0], oi.base, first, oi.size / OWN_SLOTS});
         }
     }
     return v;
@@ -1016,7 +1076,7 @@ int build_slices(g2048_ctx* c) {
         for (uint32_t o = 0; o < c->orbits.count; ++o) {
             const OrbitInfo& oi = c->orbits.o[o];
             fprintf(stderr, "[g2048 orbit %u] base %u size %u members:", o, oi.base, oi.size);
-            for (uint32_t m = 0; m < oi.nmem; ++m) fprintf(stderr, " (slot %u perm %05o)", oi.off[m], oi.perm[m]);
+            for (uint32_t m = 0; m < oi.nmem; ++m) fprintf(stderr, " (slot %u perm %06o)", oi.off[m], oi.perm[m]);
             fprintf(stderr, "\n");
         }
     if (!c->hits) {
@@ -1124,8 +1184,9 @@ int launch_td_step(g2048_ctx* c, float alpha, hipEvent_t ev = nullptr) {
         ++c->steps_since_plan;
         float* dst = c->n >= 4 ? c->D : c->w;
         BY_N(c, (k_td_update_owner<N><<<c->n_slices, OWN_WG, 0, c->stream>>>(dst, recs, B, c->slices, c->hits)));
+        if (c->n == 6)
+            k_td_update_tail<6><<<B >= (1u << 16) ? 512 : 16, OWN_WG, 0, c->stream>>>(c->D, recs, B, c->orbits.o[6].base, c->orbits.o[7].base);
         if (c->n >= 4) k_apply_orbits<<<grid_for(c->orbits.total), WG, 0, c->stream>>>(c->w, c->D, c->orbits);
-        if (c->n == 6) k_td_update_tail<6, 21><<<grid_for((uint64_t)B * 16), WG, 0, c->stream>>>(c->w, recs, B);
     } else {
         BY_N(c, (k_td_update<N><<<grid_for((uint64_t)B * 16), WG, 0, c->stream>>>(c->w, recs, B)));
     }
