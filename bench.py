@@ -176,6 +176,7 @@ def main():
     ms_play, ms_update = eng.td_steps_profiled(alpha, 20)
     st = eng.stats()
     by_play, by_update = algorithmic_bytes(n)
+    # the update is k_td_update_owner (+ k_apply_orbits, ~1 % of it; + k_td_update_tail for n = 6), timed together
     dominant = 'k_td_update' if ms_update >= ms_play else 'k_td_play'
     dom_ms = max(ms_update, ms_play)
     dom_bytes = (by_update if dominant == 'k_td_update' else by_play) * B
@@ -199,7 +200,7 @@ def main():
                                    f'{B} concurrent episodes per GPU, auto-reset',
                        'batch_per_gpu': B, 'n_tuple': n, 'alpha_effective': alpha,
                        'parallelism': f'episodes sharded over {world} GPU(s)' + (f', weight-delta all-reduce every {args.epoch} steps' if world > 1 else '')},
-            'roofline': {'bound': 'hbm', 'kernel': dominant, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'roofline': {'bound': 'hbm', 'kernel': 'k_td_update_owner' if dominant == 'k_td_update' else dominant, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          'algorithmic_bytes_per_launch': dom_bytes, 'ms_per_launch': dom_ms,
                          'ms_k_td_play': ms_play, 'ms_k_td_update': ms_update,
