@@ -610,7 +610,7 @@ __device__ __forceinline__ void lds_add_folded(float* acc, uint32_t local, float
     if (hit) atomicAdd(&acc[local], dw);
 }
 
-template <int N, int F0, int FC>
+template <int N, int F0, int FC, bool FB>
 __device__ __forceinline__ void own_accum(const Packed& p, float dw, bool valid, float* acc, const Slice& sl, uint32_t& nhit, float* D,
                                           uint32_t* fb_hits) {
     constexpr int F = Shape<N>::F;
@@ -627,7 +627,7 @@ __device__ __forceinline__ void own_accum(const Packed& p, float dw, bool valid,
             else if (hit)
                 atomicAdd(&acc[local], dw);
             nhit += hit ? 1u : 0u;
-            if (N >= 4 && sl.fb_mask && valid && !hit) {
+            if (FB && valid && !hit) {
                 const uint32_t rel = s[f] - sl.orb_tlo, ch = rel / OWN_SLOTS;
                 if ((sl.fb_mask >> ch) & 1u) {
                     __hip_atomic_fetch_add(&D[sl.orb_dlo + rel], dw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -638,7 +638,7 @@ __device__ __forceinline__ void own_accum(const Packed& p, float dw, bool valid,
     }
 }
 
-template <int N, int V>
+template <int N, int V, bool FB>
 __device__ __forceinline__ void own_run(float* acc, const Slice& s, const TdRecs& recs, uint32_t B, uint32_t* hits, float* D, uint32_t* fb_hits) {
     constexpr int F0 = OwnVariants<N>::f0(V), FC = OwnVariants<N>::fc(V), OWN_UNROLL = OwnUnroll<FC>::U;
     uint32_t nhit = 0;
@@ -657,7 +657,7 @@ __device__ __forceinline__ void own_run(float* acc, const Slice& s, const TdRecs
                 dw[u] = ok ? recs.dw1[rr] : 0.0f;
             }
 #pragma unroll
-            for (int u = 0; u < OWN_UNROLL; ++u) own_accum<N, F0, FC>(unpack4(st[u]), dw[u], dw[u] != 0.0f, acc, s, nhit, D, fb_hits);
+            for (int u = 0; u < OWN_UNROLL; ++u) own_accum<N, F0, FC, FB>(unpack4(st[u]), dw[u], dw[u] != 0.0f, acc, s, nhit, D, fb_hits);
         }
     }
     {   // terminal queue
@@ -667,7 +667,7 @@ __device__ __forceinline__ void own_run(float* acc, const Slice& s, const TdRecs
             const uint32_t r = base0 + threadIdx.x;
             const bool ok = r < end;
             const uint32_t rr = ok ? r : end - 1;
-            own_accum<N, F0, FC>(ld_packed(recs.qstate, rr), recs.qdw[rr], ok, acc, s, nhit, D, fb_hits);
+            own_accum<N, F0, FC, FB>(ld_packed(recs.qstate, rr), recs.qdw[rr], ok, acc, s, nhit, D, fb_hits);
         }
     }
     // load statistics for the planner: one counter bump per wave
@@ -680,9 +680,14 @@ template <int N, int V>
 __device__ __forceinline__ void own_dispatch(float* acc, const Slice& s, const TdRecs& recs, uint32_t B, uint32_t* hits, float* D,
                                              uint32_t* fb_hits) {
     if constexpr (V < OwnVariants<N>::COUNT) {
-        if (s.variant == (uint32_t)V)
-            own_run<N, V>(acc, s, recs, B, hits, D, fb_hits);
-        else
+        if (s.variant == (uint32_t)V) {
+            // the fallback duty (global atomics for chunks nobody holds in LDS) is carried by few workgroups: two
+            // instantiations keep its tests out of everybody else's inner loop
+            if (N >= 4 && s.fb_mask)
+                own_run<N, V, true>(acc, s, recs, B, hits, D, fb_hits);
+            else
+                own_run<N, V, false>(acc, s, recs, B, hits, D, fb_hits);
+        } else
             own_dispatch<N, V + 1>(acc, s, recs, B, hits, D, fb_hits);
     }
 }
