@@ -520,7 +520,6 @@ struct Slice {
     uint32_t dlo;           // where the slice is added at flush time: index into the orbit table D (n >= 4) or into w (n = 2, 3)
     uint32_t part, nparts;  // records [count * part / nparts, count * (part + 1) / nparts)
     uint32_t chunk;         // hit counter of this slice (load statistics for the planner)
-    uint32_t fold;          // fold same-slot lanes of a wave before the LDS add (lds_add_folded)
     // Chunks of the same orbit table that nobody holds in LDS (they see too few adds to be worth a record scan) are
     // added straight into D with global atomics by the orbit's busiest chunk: bit k of fb_mask = chunk k of the orbit
     // is this workgroup's duty.  orb_tlo / orb_dlo / chunk0: first table slot, first D index, first hit counter of the orbit.
@@ -572,7 +571,10 @@ constexpr uint32_t OWN_SLOTS = 32768;      // 128 KiB of the CU's 160 KiB LDS
 template <int FC> struct OwnUnroll { static constexpr int U = FC == 1 ? 4 : 1; };   // records in flight per thread (loads issued together)
 
 // variant v of table N covers features [f0(v), f0(v) + fc(v))
-template <int N> struct OwnVariants { static constexpr int COUNT = Shape<N>::F < 21 ? Shape<N>::F : 21; static constexpr int f0(int v) { return v; } static constexpr int fc(int) { return 1; } };
+// n >= 4: one variant per LDS-owned orbit, encoding the orbit's representative feature (outer line 0, inner line 1,
+// corner square 8, edge square 9, centre square 12, cross 17; find_orbits checks that these are the representatives)
+constexpr int ORBIT_REPS[6] = {0, 1, 8, 9, 12, 17};
+template <int N> struct OwnVariants { static constexpr int COUNT = N == 4 ? 5 : 6; static constexpr int f0(int v) { return ORBIT_REPS[v]; } static constexpr int fc(int) { return 1; } };
 template <> struct OwnVariants<2> { static constexpr int COUNT = 1; static constexpr int f0(int) { return 0; } static constexpr int fc(int) { return 24; } };
 template <> struct OwnVariants<3> { static constexpr int COUNT = 7; static constexpr int f0(int v) { return 8 * v; } static constexpr int fc(int v) { return v < 6 ? 8 : 4; } };
 
@@ -581,33 +583,6 @@ __device__ __forceinline__ Packed unpack4(const uint4& v) {
     q.R[0] = v.x & 0xFFFFu; q.R[1] = v.x >> 16; q.R[2] = v.y & 0xFFFFu; q.R[3] = v.y >> 16;
     q.C[0] = v.z & 0xFFFFu; q.C[1] = v.z >> 16; q.C[2] = v.w & 0xFFFFu; q.C[3] = v.w >> 16;
     return q;
-}
-
-// One LDS add per lane — but first fold lanes that target the SAME slot: the LDS serialises same-address atomics,
-// and young boards put most of a wave on one slot (an empty line is index 0 of its table).  Up to two rounds: take
-// the slot of the first pending lane; if at least 8 lanes share it, sum their dw across the wave and issue one add.
-// Must be called by all 64 lanes of the wave (`hit` false for lanes with nothing to add).
-__device__ __forceinline__ void lds_add_folded(float* acc, uint32_t local, float dw, bool hit) {
-    bool fold = true;
-#pragma unroll
-    for (int round = 0; round < 2; ++round) {
-        const unsigned long long pending = __ballot(hit);
-        if (fold && pending != 0) {                 // wave-uniform
-            const int first = __ffsll((long long)pending) - 1;
-            const uint32_t lead = (uint32_t)__builtin_amdgcn_readlane((int)local, first);
-            const bool same = hit && local == lead;
-            if (__popcll(__ballot(same)) >= 8) {
-                float v = same ? dw : 0.0f;
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-                if ((int)(threadIdx.x & 63) == first) atomicAdd(&acc[lead], v);
-                hit = hit && !same;
-            } else {
-                fold = false;
-            }
-        }
-    }
-    if (hit) atomicAdd(&acc[local], dw);
 }
 
 template <int N, int F0, int FC, bool FB>
@@ -622,10 +597,7 @@ __device__ __forceinline__ void own_accum(const Packed& p, float dw, bool valid,
         for (int f = F0; f < F0 + FC; ++f) {
             const uint32_t local = s[f] - sl.tlo;
             const bool hit = valid && local < sl.size;
-            if (sl.fold)
-                lds_add_folded(acc, local, dw, hit);
-            else if (hit)
-                atomicAdd(&acc[local], dw);
+            if (hit) atomicAdd(&acc[local], dw);
             nhit += hit ? 1u : 0u;
             if (FB && valid && !hit) {
                 const uint32_t rel = s[f] - sl.orb_tlo, ch = rel / OWN_SLOTS;
@@ -643,7 +615,7 @@ __device__ __forceinline__ void own_run(float* acc, const Slice& s, const TdRecs
     constexpr int F0 = OwnVariants<N>::f0(V), FC = OwnVariants<N>::fc(V), OWN_UNROLL = OwnUnroll<FC>::U;
     uint32_t nhit = 0;
     {   // main records: this part's share of the lanes, OWN_UNROLL records per thread in flight; the loop bounds are
-        // wave-uniform so that every lane reaches lds_add_folded
+        // wave-uniform
         const uint32_t begin = (uint32_t)((uint64_t)B * s.part / s.nparts), end = (uint32_t)((uint64_t)B * (s.part + 1) / s.nparts);
         for (uint32_t base0 = begin; base0 < end; base0 += OWN_WG * OWN_UNROLL) {
             uint4 st[OWN_UNROLL];
@@ -1057,8 +1029,9 @@ std::vector<ChunkInfo> table_chunks(const g2048_ctx* c) {
             for (int j = 0; j < 21 && j < c->F; ++j)
                 if (feature_offset(c->n, j) == oi.off[0]) rep = (uint32_t)j;
             const uint32_t first = (uint32_t)v.size();
+            if (o >= 6 || (int)rep != ORBIT_REPS[o]) return {};      // (checked by the caller: empty plan = unexpected orbit structure)
             for (uint32_t lo = 0; lo < oi.size; lo += OWN_SLOTS)
-                v.push_back({rep, oi.off[0] + lo, OWN_SLOTS, oi.base + lo, oi.digits == 4 ? 1.0 : 2.0, oi.off[0], oi.base, first, oi.size / OWN_SLOTS});
+                v.push_back({o, oi.off[0] + lo, OWN_SLOTS, oi.base + lo, oi.digits == 4 ? 1.0 : 2.0, oi.off[0], oi.base, first, oi.size / OWN_SLOTS});
         }
     }
     return v;
@@ -1077,6 +1050,7 @@ int build_slices(g2048_ctx* c) {
     }
     const std::vector<ChunkInfo> chunks = table_chunks(c);
     const size_t nc = chunks.size();
+    if (nc == 0) return fail(c, G2048_ERR_STATE, "unexpected orbit structure");
     if (!c->hits && getenv("G2048_DEBUG_PLAN"))
         for (uint32_t o = 0; o < c->orbits.count; ++o) {
             const OrbitInfo& oi = c->orbits.o[o];
@@ -1130,17 +1104,13 @@ int build_slices(g2048_ctx* c) {
             ++n_lds;
         }
     const uint32_t budget = c->B < (1u << 14) ? (uint32_t)n_lds : (WG_BUDGET > n_lds ? WG_BUDGET : (uint32_t)n_lds);
-    // Folding same-slot lanes before the LDS add costs ~0.3 ms per step in steady state and saves ~0.1 ms in the worst
-    // phase (all games young and in step): off unless asked for (measured: DESIGN.md section 4).
-    uint32_t fold = 0;
-    if (const char* e = getenv("G2048_FOLD")) fold = (uint32_t)atoi(e);
     std::vector<Slice> v;
     std::vector<uint32_t> parts(nc, 0);
     for (size_t k = 0; k < nc; ++k) {
         if (!in_lds[k]) continue;
         parts[k] = 1 + (uint32_t)((budget - n_lds) * cost[k] / total);
         for (uint32_t p = 0; p < parts[k]; ++p)
-            v.push_back(Slice{chunks[k].variant, chunks[k].tlo, chunks[k].size, chunks[k].dlo, p, parts[k], (uint32_t)k, fold, duty[k],
+            v.push_back(Slice{chunks[k].variant, chunks[k].tlo, chunks[k].size, chunks[k].dlo, p, parts[k], (uint32_t)k, duty[k],
                               chunks[k].orb_tlo, chunks[k].orb_dlo, chunks[k].chunk0});
     }
     if (v.size() > MAX_SLICES) return fail(c, G2048_ERR_STATE, "LDS-owner plan too large");
