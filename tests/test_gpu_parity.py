@@ -383,6 +383,65 @@ def test_td_auto_reset_and_stats_consistency():
     eng.close()
 
 
+def test_weight_delta_protocol_on_device():
+    """g2048_delta_begin / extract / apply (the per-epoch all-reduce plumbing): D = W - W0 is exactly what the epoch's
+    steps added, and W0 + k*D rebuilds the table a k-rank sum all-reduce would produce."""
+    import ctypes
+    n, B = 4, 8192
+    eng = Engine(B, n=n, seed=21)
+    w0 = formulas.weights(n, scale=2.0 ** -5)
+    eng.set_weights(w0)
+    eng.delta_begin()
+    eng.td_steps(2.0 ** -16, 3)
+    w1 = eng.get_weights()
+    assert np.abs(w1 - w0).max() > 0
+    eng.delta_extract()                                                      # into the context's own buffer
+    eng.delta_apply()                                                        # one rank: W = W0 + D = W
+    assert np.allclose(eng.get_weights(), w1, rtol=1e-6, atol=1e-7)      # fp32: W0 + (W - W0)
+    # a second epoch measures from the new snapshot
+    eng.td_steps(2.0 ** -16, 2)
+    w2 = eng.get_weights()
+    eng.delta_extract()
+    eng.delta_apply()
+    assert np.allclose(eng.get_weights(), w2, rtol=1e-6, atol=1e-7)
+    ptr, count = eng.weights_ptr()
+    assert ptr and count == formulas.table_size(n) and eng.delta_ptr()
+    eng.timer_start()
+    eng.td_steps(0.0, 2)
+    assert eng.timer_stop() > 0
+    eng.close()
+
+
+def test_shared_table_contexts_and_last_move():
+    """g2048_create_shared: a second set of lanes over the same table sees the first one's updates;
+    g2048_get_last_move reports direction / new tile / end of game of every lane."""
+    n = 3
+    main = Engine(2048, n=n, seed=4)
+    main.set_weights(formulas.weights(n, scale=2.0 ** -6))
+    solo = Engine(1, seed=99, lane0=1 << 40, share_table_of=main)
+    solo.set_auto_reset(False)
+    probe = np.array([[1, 2, 3, 4], [0, 5, 1, 0], [2, 2, 11, 15], [14, 13, 0, 1]], np.uint8)
+    solo.set_boards(probe[None])
+    v0 = solo.evaluate()[0]
+    main.update(probe[None], [0.5])
+    solo.set_boards(probe[None])
+    assert abs(solo.evaluate()[0] - (v0 + 0.5 * 52)) < 1e-3                  # identity image adds dw to each of the 52 slots
+    solo.reset()
+    before = solo.get_boards()[0].copy()
+    solo.td_steps(0.1, 1)
+    lm = int(solo.last_move()[0])
+    assert lm & 4 and lm & (1 << 10)
+    after, reward, changed = rb.move_all(before[None])
+    d = lm & 3
+    assert changed[0, d]
+    cell, tile = (lm >> 4) & 15, (lm >> 8) & 3
+    want = after[0, d].copy()
+    want[cell >> 2, cell & 3] = tile
+    assert np.array_equal(solo.get_boards()[0], want) and solo.get_scores()[0] == reward[0, d]
+    solo.close()
+    main.close()
+
+
 # ------------------------------------------------------------------ error behaviour
 
 def test_error_codes():
