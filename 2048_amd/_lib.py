@@ -59,6 +59,8 @@ SIGNATURES = {
     'g2048_terminal': (c_int, [_P, _P, _P, _P]),
     'g2048_spawn': (c_int, [_P, _P, _P]),
     'g2048_spawn_injected': (c_int, [_P, _P, _P]),
+    'g2048_boards_move_all': (c_int, [_P, _P, c_int64, _P, _P, _P]),
+    'g2048_boards_evaluate': (c_int, [_P, _P, c_int64, _P]),
     'g2048_step_random': (c_int, [_P, c_uint32]),
     'g2048_features': (c_int, [_P, _P]),
     'g2048_weights_set': (c_int, [_P, _P, c_int64]),

@@ -226,8 +226,7 @@ class QAgent:
     # ---- value and update of one board (r_learning.py:202-214)
 
     def evaluate(self, row, score=None):
-        self.solo.set_boards(np.asarray(row, dtype=np.uint8).reshape(1, 4, 4), clear_carry=False)
-        return float(self.solo.evaluate()[0])
+        return float(self.engine.boards_evaluate(np.asarray(row, dtype=np.uint8).reshape(1, 4, 4))[0])
 
     def update(self, row, dw):
         self.engine.update(np.asarray(row, dtype=np.uint8).reshape(1, 4, 4), np.array([dw], np.float32))

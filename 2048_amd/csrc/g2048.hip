@@ -1468,6 +1468,44 @@ int g2048_spawn_injected(g2048_ctx* c, const uint8_t* r10, const uint8_t* k) {
     return spawn_impl(c, r10, k, nullptr, nullptr);
 }
 
+// ---- stateless forms: any number of caller-supplied boards, the lanes are not touched (Game.pre_move / game_over and
+// QAgent.evaluate on arbitrary positions, e.g. the nodes of the look-ahead tree, game_logic.py:214-243)
+int g2048_boards_move_all(g2048_ctx* c, const uint8_t* boards, int64_t count, uint8_t* after, int32_t* reward, uint8_t* changed) {
+    if (!c || !boards || !after || !reward || !changed) return c ? fail(c, G2048_ERR_ARG, "null buffer") : G2048_ERR_ARG;
+    NEED(c, count >= 0 && count <= (1 << 28), "bad board count");
+    if (count == 0) return G2048_OK;
+    if (int rc = bind(c)) return rc;
+    const size_t n = (size_t)count;
+    if (int rc = ensure_scratch(c, n * (16 + 64 + 16 + 1))) return rc;
+    uint4* d_boards = (uint4*)c->scratch;
+    uint4* d_after = d_boards + n;
+    int4* d_reward = (int4*)(d_after + 4 * n);
+    uint8_t* d_changed = (uint8_t*)(d_reward + n);
+    int rc;
+    if ((rc = h2d(c, d_boards, boards, n * 16))) return rc;
+    k_move_all<<<grid_for(n), WG, 0, c->stream>>>(d_boards, (uint32_t)n, d_after, d_reward, d_changed);
+    if ((rc = launched(c, "k_move_all"))) return rc;
+    if ((rc = d2h(c, after, d_after, n * 64)) || (rc = d2h(c, reward, d_reward, n * 16)) || (rc = d2h(c, changed, d_changed, n))) return rc;
+    return G2048_OK;
+}
+
+int g2048_boards_evaluate(g2048_ctx* c, const uint8_t* boards, int64_t count, float* value) {
+    if (!c || !boards || !value) return c ? fail(c, G2048_ERR_ARG, "null buffer") : G2048_ERR_ARG;
+    NEED_TABLE(c);
+    NEED(c, count >= 0 && count <= (1 << 28), "bad board count");
+    if (count == 0) return G2048_OK;
+    if (int rc = bind(c)) return rc;
+    const size_t n = (size_t)count;
+    if (int rc = ensure_scratch(c, n * 20)) return rc;
+    uint4* d_boards = (uint4*)c->scratch;
+    float* d_value = (float*)(d_boards + n);
+    int rc;
+    if ((rc = h2d(c, d_boards, boards, n * 16))) return rc;
+    BY_N(c, (k_evaluate<N><<<grid_for(n), WG, 0, c->stream>>>(d_boards, (uint32_t)n, c->w, d_value)));
+    if ((rc = launched(c, "k_evaluate"))) return rc;
+    return d2h(c, value, d_value, n * 4);
+}
+
 int g2048_step_random(g2048_ctx* c, uint32_t nsteps) {
     if (!c) return G2048_ERR_ARG;
     if (int rc = bind(c)) return rc;

@@ -135,6 +135,23 @@ class Engine:
         kk = np.ascontiguousarray(k, np.uint8).reshape(self.batch)
         self._c(self.lib.g2048_spawn_injected(self.ctx, _buf(r), _buf(kk)))
 
+    def boards_move_all(self, boards):
+        """Stateless: (after[n,4,4,4], reward[n,4], changed[n]) of any number of boards."""
+        b = np.ascontiguousarray(np.asarray(boards).reshape(-1, 16), np.uint8)
+        n = len(b)
+        after = np.empty((n, 4, 4, 4), np.uint8)
+        reward = np.empty((n, 4), np.int32)
+        changed = np.empty(n, np.uint8)
+        self._c(self.lib.g2048_boards_move_all(self.ctx, _buf(b), n, _buf(after), _buf(reward), _buf(changed)))
+        return after, reward, changed
+
+    def boards_evaluate(self, boards):
+        """Stateless: V(board) for any number of boards with this context's table."""
+        b = np.ascontiguousarray(np.asarray(boards).reshape(-1, 16), np.uint8)
+        v = np.empty(len(b), np.float32)
+        self._c(self.lib.g2048_boards_evaluate(self.ctx, _buf(b), len(b), _buf(v)))
+        return v
+
     def step_random(self, nsteps):
         self._c(self.lib.g2048_step_random(self.ctx, int(nsteps)))
 

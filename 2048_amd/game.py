@@ -10,7 +10,7 @@ import threading
 from .start import *  # noqa: F401,F403  (the reference's modules star-import start.py the same way)
 from .start import GAME_PANE, Thread, np, pickle, random
 
-from . import _lib
+from . import _lib, lookahead
 from .engine import Engine
 
 
@@ -44,9 +44,7 @@ class _Device:
         key = b.tobytes()
         with self.lock:
             if key != self.key:
-                eng = self.engine()
-                eng.set_boards(b.reshape(1, 4, 4))
-                after, reward, changed = eng.move_all()
+                after, reward, changed = self.engine().boards_move_all(b.reshape(1, 4, 4))
                 self.key, self.moves = key, (after[0].astype(np.int32), reward[0], int(changed[0]))
             return self.moves
 
@@ -55,12 +53,18 @@ class _Device:
         with self.lock:
             eng = self.engine()
             eng.set_boards(b.reshape(1, 4, 4))
-            self.key = None
             over, n_empty, n_pairs = eng.terminal()
             return bool(over[0]), int(n_empty[0]), int(n_pairs[0])
 
 
 _DEVICE = _Device()
+_SAMPLER = []
+
+
+def _sampler():
+    if not _SAMPLER:
+        _SAMPLER.append(lookahead.random_sampler())
+    return _SAMPLER[0]
 
 
 def create_table():
@@ -201,6 +205,20 @@ class Game:
         """First maximum over the directions that change the board (game_logic.py:150-161)."""
         best = (0, None, None)
         best_value = -np.inf
+        engine = getattr(getattr(estimator, '__self__', None), 'engine', None)
+        if depth > 0 and engine is not None and getattr(estimator, '__name__', '') == 'evaluate':
+            # the estimator is a device agent: the whole look-ahead tree of the four candidates is evaluated level by
+            # level in batches (2048_amd/lookahead.py) instead of node by node
+            after, reward, changed = _DEVICE.move_all(self.row)
+            dirs = [d for d in range(4) if (changed >> d) & 1]
+            if not dirs:
+                return best
+            values = lookahead.expectimax_values(engine, after[dirs].astype(np.uint8), depth, width, since_empty, _sampler())
+            Game.counter += 4
+            for d, value in zip(dirs, values):
+                if value > best_value:
+                    best_value, best = value, (d, after[d].copy(), self.score + int(reward[d]))
+            return best
         for direction in range(4):
             cand_row, cand_score, changed = self.pre_move(self.row, self.score, direction)
             if not changed:

@@ -94,6 +94,11 @@ int g2048_terminal(g2048_ctx* ctx, uint8_t* over, uint8_t* n_empty, uint8_t* n_p
  * The (r10, k) draws used are exported so the same game can be replayed into the reference. */
 int g2048_spawn(g2048_ctx* ctx, uint8_t* r10 /* [B] or NULL */, uint8_t* k /* [B] or NULL */);
 int g2048_spawn_injected(g2048_ctx* ctx, const uint8_t* r10 /* [B] */, const uint8_t* k /* [B] */);
+/* Stateless form of g2048_move_all for `count` caller-supplied boards (the lanes are not touched): Game.pre_move x 4
+ * on arbitrary positions, e.g. the nodes of the look-ahead tree (game_logic.py:214-243).  changed == 0 with no empty
+ * cell is game over. */
+int g2048_boards_move_all(g2048_ctx* ctx, const uint8_t* boards /* [count][16] */, int64_t count, uint8_t* after /* [count][4][16] */,
+                          int32_t* reward /* [count][4] */, uint8_t* changed /* [count] */);
 /* nsteps x {uniformly random valid direction, move, spawn, terminal check / auto-reset}: BASELINE config 2 */
 int g2048_step_random(g2048_ctx* ctx, uint32_t nsteps);
 
@@ -103,6 +108,8 @@ int g2048_weights_set(g2048_ctx* ctx, const float* w, int64_t count);     /* fla
 int g2048_weights_get(g2048_ctx* ctx, float* w, int64_t count);
 int g2048_weights_init(g2048_ctx* ctx, uint64_t seed, float scale);       /* U[0, scale): init_weights :139-149 uses 0.01 */
 int g2048_evaluate(g2048_ctx* ctx, float* value /* [B] */);               /* QAgent.evaluate, r_learning.py:202-203 */
+/* the same for `count` caller-supplied boards (the lanes are not touched) */
+int g2048_boards_evaluate(g2048_ctx* ctx, const uint8_t* boards /* [count][16] */, int64_t count, float* value /* [count] */);
 /* greedy afterstate choice (r_learning.py:229-237, game_logic.py:150-161 at depth 0): first maximum over the
  * directions that change the board; action 255 / value 0 when none does.  values4 ([B][4], may be NULL) gets
  * V(afterstate d) or -inf.  value and action may both be NULL: the kernel runs and nothing is copied back. */

@@ -136,3 +136,74 @@ def test_batched_training_learns(api):
     early, late = np.mean(hist[:3]), np.mean(hist[-3:])
     assert late > 2.0 * early, (early, late)
     assert any('average over last 1000 episodes' in str(ln) for ln in logs)
+
+
+def test_batched_look_forward_matches_the_reference_recursion(api):
+    """Game.look_forward semantics (game_logic.py:214-243) on the batched path: with a sampler keyed by the board
+    (so that both sides draw the same tiles whatever their visiting order) the values equal a node-by-node recursion
+    written with the oracle's moves."""
+    import importlib
+    lookahead = importlib.import_module('2048_amd.lookahead')
+    n = 3
+    agent = api.QAgent(name='t', storage='local', console='local', n=n, with_weights=False)
+    w = formulas.weights(n)
+    offs, _ = rs.feature_offsets(n)
+    agent.weights = [w[o:o + s] for o, s in zip(offs, formulas.feature_sizes(n))]
+    w64 = w.astype(np.float64)
+
+    def draws_for(board, k):                                 # deterministic in the board only
+        r = np.random.RandomState(int.from_bytes(np.ascontiguousarray(board, np.uint8).tobytes()[:8], 'little') % (2 ** 31))
+        empties = np.nonzero(np.asarray(board).reshape(16) == 0)[0]
+        cells = r.permutation(empties)[:k]
+        tiles = np.where(r.rand(k) < 0.1, 2, 1)
+        return cells, tiles
+
+    def sampler(rows, k):
+        kmax = int(k.max())
+        cells = np.full((len(rows), kmax), -1, np.int64)
+        tiles = np.ones((len(rows), kmax), np.int64)
+        for i, (row, kk) in enumerate(zip(rows, k)):
+            cells[i, :kk], tiles[i, :kk] = draws_for(row, int(kk))
+        return cells, tiles
+
+    def recurse(row, depth, width, since_empty):             # the reference's recursion, node by node, float64
+        if depth == 0:
+            return rb.evaluate(n, w64, row[None])[0]
+        n_empty = int((row == 0).sum())
+        if n_empty >= since_empty:
+            return rb.evaluate(n, w64, row[None])[0]
+        k = min(width, n_empty)
+        cells, tiles = draws_for(row, k)
+        total = 0.0
+        for cell, tile in zip(cells, tiles):
+            child = row.copy().reshape(16)
+            child[cell] = tile
+            child = child.reshape(4, 4)
+            if rb.game_over(child[None])[0]:
+                best = -100
+            else:
+                best = -np.inf
+                for d in range(4):
+                    nxt, _, changed = rb.move(child[None], d)
+                    if changed[0]:
+                        best = max(best, recurse(nxt[0], depth - 1, width, since_empty))
+            total += max(best, 0)
+        return total / k
+
+    boards = golden_boards_for_lookahead()
+    for depth, width, since_empty in ((1, 2, 16), (2, 3, 6), (3, 2, 8)):
+        got = lookahead.expectimax_values(agent.engine, boards, depth, width, since_empty, sampler)
+        want = np.array([recurse(b, depth, width, since_empty) for b in boards])
+        assert np.allclose(got, want, rtol=1e-5, atol=1e-5), (depth, width, since_empty)
+    # and through the Game API: a device agent with depth > 0 takes the batched path and returns a legal best move
+    game = api.Game(row=boards[3].astype(np.int32))
+    best_dir, best_row, best_score = game._find_best_move(agent.evaluate, 2, 3, 8)
+    new_row, new_score, changed = game.pre_move(game.row, game.score, best_dir)
+    assert changed and np.array_equal(best_row, new_row) and best_score == new_score
+
+
+def golden_boards_for_lookahead():
+    from tests.conftest import load_golden
+    g = load_golden('moves.npz')
+    b = g['boards'][(g['game_over'] == 0) & (g['empty_count'] > 0) & (g['boards'].reshape(len(g['boards']), 16).max(axis=1) < 12)]
+    return np.ascontiguousarray(b[::97][:24])
