@@ -13,6 +13,8 @@ the per-game learning rate is divided accordingly: alpha_device = alpha * num_fe
 from .game import *  # noqa: F401,F403  (r_learning.py:3 star-imports game_logic the same way)
 from .game import Game, np, pickle, time, deque, load_s3, save_s3, Logger, AGENT_PANE, RUNNING, dash_intervals
 
+import os
+
 from .engine import Engine, NUM_FEAT, feature_layout
 
 
@@ -353,7 +355,8 @@ class QAgent:
     def device_alpha(self, lanes=None):
         """The batch rule: alpha for g2048_td_steps when `lanes` episodes learn concurrently."""
         lanes = self.batch if lanes is None else lanes
-        return self.alpha if lanes == 1 else self.alpha * self.num_feat / (8.0 * lanes)
+        mult = float(os.environ.get('G2048_ALPHA_MULT', '1'))          # (experiments with the batch rule)
+        return self.alpha if lanes == 1 else mult * self.alpha * self.num_feat / (8.0 * lanes)
 
     def _train_run_batched(self, num_eps, saving, stopper, chunk=64):
         """train_run on `batch` concurrent episodes: the same schedule and logs, driven by the device's episode
