@@ -72,6 +72,9 @@ SIGNATURES = {
     'g2048_td_steps': (c_int, [_P, c_float, c_uint32]),
     'g2048_set_update_mode': (c_int, [_P, c_int]),
     'g2048_get_last_move': (c_int, [_P, _P]),
+    'g2048_log_enable': (c_int, [_P, c_uint32, c_uint32]),
+    'g2048_log_meta': (c_int, [_P, _P]),
+    'g2048_log_game': (c_int, [_P, c_uint32, c_uint32, _P, _P]),
     'g2048_stats_get': (c_int, [_P, POINTER(Stats)]),
     'g2048_stats_reset': (c_int, [_P]),
     'g2048_weights_device_ptr': (c_int, [_P, POINTER(_P), POINTER(c_int64)]),

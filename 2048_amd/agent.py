@@ -358,12 +358,51 @@ class QAgent:
         mult = float(os.environ.get('G2048_ALPHA_MULT', '1'))          # (experiments with the batch rule)
         return self.alpha if lanes == 1 else mult * self.alpha * self.num_feat / (8.0 * lanes)
 
+    WATCHED_LANES, LOG_CAPACITY = 1024, 16384
+
+    def _game_from_log(self, eng, lane, slot, length, score):
+        """Rebuild a reference `Game` (moves, tiles, starting_position, final row) from a device game record."""
+        words, start = eng.log_game(lane, slot)
+        game = Game(row=start.astype(np.int32))
+        game.starting_position = start.astype(np.int32)
+        for lm in words[:length]:
+            lm = int(lm)
+            game.make_move(lm & 3)
+            if lm & (1 << 10):
+                cell = ((lm >> 4) & 15) >> 2, ((lm >> 4) & 15) & 3
+                game.row[cell] = (lm >> 8) & 3
+                game.tiles.append(((lm >> 8) & 3, cell))
+        game.moves.append(-1)
+        assert game.score == score, 'device game record does not replay to its score'
+        return game
+
+    def _collect_best_games(self, eng, seen, saving):
+        """Look at the games the watched lanes finished since the last call; keep the best one as top_game."""
+        meta = eng.log_meta()
+        best = None
+        for lane in np.nonzero(meta[:, 2] != seen)[0]:
+            slot = int(meta[lane, 0]) ^ 1                      # the slot that just finished
+            length, score, flags = int(meta[lane, 3 + 2 * slot]), int(meta[lane, 4 + 2 * slot]), int(meta[lane, 7])
+            if length and not (flags >> slot) & 5 and (best is None or score > best[0]):
+                best = (score, int(lane), slot, length)
+        seen[:] = meta[:, 2]
+        if best is not None and (self.top_game is None or best[0] > self.top_game.score):
+            self.top_game = self._game_from_log(eng, best[1], best[2], best[3], best[0])
+            self.print(f'\nnew best recorded game at episode {self.step}!\n{self.top_game}\n')
+            if saving:
+                self.save_game(self.top_game)
+                self.print(f'game saved at {self.game_file}')
+
     def _train_run_batched(self, num_eps, saving, stopper, chunk=64):
         """train_run on `batch` concurrent episodes: the same schedule and logs, driven by the device's episode
-        counters.  Per-game records (best game, exact ma_100 of consecutive games) need per-lane logs and are
-        not kept here; averages are over the games that finished in each reporting window."""
+        counters; averages are over the games that finished in each reporting window.  `top_score` is the best score
+        of all lanes; `top_game` (a replayable Game, as the reference keeps) is the best game among the first
+        WATCHED_LANES lanes, whose moves and tiles the device records."""
         eng = self.engine
         eng.set_auto_reset(True)
+        watched = min(self.batch, self.WATCHED_LANES)
+        eng.log_enable(watched, self.LOG_CAPACITY)
+        seen = np.zeros(watched, np.uint32)
         if stopper:
             parent, this_thread = stopper['parent'], stopper['a']
         global_start = start = benchmark_time = time.time()
@@ -388,6 +427,7 @@ class QAgent:
             st = eng.stats()
             self.step = base + st['episodes']
             self.top_score = max(self.top_score, st['best_score'])
+            self._collect_best_games(eng, seen, saving)
             top = max([t for t, cnt in enumerate(st['max_tile']) if cnt] or [0])
             if top > self.top_tile:
                 self.top_tile = top

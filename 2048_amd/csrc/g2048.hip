@@ -410,13 +410,61 @@ __device__ __forceinline__ void push_terminal(const TdRecs& r, const Packed& sta
     r.qdw[slot] = dw;
 }
 
+// Optional per-lane game records for the first `lanes` lanes (Game.moves / Game.tiles / starting_position of
+// game_logic.py:55-66, what Game.replay and show.py's replay need).  Two slots per lane: while one game is being
+// written the previous, finished one stays readable.
+struct GameLog {
+    uint32_t lanes, capacity;       // lanes == 0: off
+    uint16_t* moves;                // [lanes][2][capacity] g2048_get_last_move words, one per move
+    uint4* start;                   // [lanes][2] starting boards
+    uint32_t* meta;                 // [lanes][8]: slot in use, moves so far, games finished, {length, score} of slot 0, of slot 1, flags
+};
+constexpr uint32_t LOG_PARTIAL0 = 1u, LOG_TRUNC0 = 4u;     // flags: bit s = slot s did not start at move 0; bit 2 + s = slot s overflowed
+
+__global__ __launch_bounds__(WG) void k_log_init(GameLog lg, const uint4* boards, const uint8_t* flags) {
+    uint32_t i = blockIdx.x * WG + threadIdx.x;
+    if (i >= lg.lanes) return;
+    uint32_t* m = lg.meta + 8 * i;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m[j] = 0;
+    m[7] = (flags[i] & HAS_PREV) ? LOG_PARTIAL0 : 0u;       // a game already under way cannot be replayed from its start
+    lg.start[2 * i] = boards[i];
+}
+
+__device__ __forceinline__ void log_step(const GameLog& lg, uint32_t i, uint32_t lm, bool moved, bool over, int32_t final_score,
+                                         bool restarted, const Board& fresh) {
+    uint32_t* m = lg.meta + 8 * i;
+    uint32_t slot = m[0], cnt = m[1];
+    if (moved) {
+        if (cnt < lg.capacity)
+            lg.moves[((size_t)i * 2 + slot) * lg.capacity + cnt] = (uint16_t)lm;
+        else
+            m[7] |= LOG_TRUNC0 << slot;
+        ++cnt;
+    }
+    if (over) {
+        m[3 + 2 * slot] = cnt;
+        m[4 + 2 * slot] = (uint32_t)final_score;
+        m[2] += 1;
+        if (restarted) {
+            slot ^= 1u;
+            cnt = 0;
+            m[3 + 2 * slot] = 0;
+            m[7] &= ~((LOG_PARTIAL0 | LOG_TRUNC0) << slot);
+            st_board(lg.start, (size_t)i * 2 + slot, fresh);
+        }
+    }
+    m[0] = slot;
+    m[1] = cnt;
+}
+
 // Step part 1 — the body of `while not game.game_over` in QAgent.episode (r_learning.py:228-246) for every live
 // lane, all reading the same table.  `prev` is double-buffered: prev_cur holds `state`, prev_nxt receives this
 // step's afterstate, so the main record needs no copy.
 template <int N>
 __global__ __launch_bounds__(WG) void k_td_play(uint4* boards, int32_t* scores, ulonglong2* rng, uint4* prev_nxt, float* label, uint8_t* flags,
                                                 uint32_t B, const float* __restrict__ w, float alpha, TdRecs recs, int auto_reset,
-                                                Stats* stats, uint16_t* last_move) {
+                                                Stats* stats, uint16_t* last_move, GameLog lg) {
     constexpr float F = (float)Shape<N>::F;
     __shared__ WgStats ws;
     wg_stats_init(&ws);
@@ -466,6 +514,7 @@ __global__ __launch_bounds__(WG) void k_td_play(uint4* boards, int32_t* scores, 
                 prev_nxt[i] = recs.state1[i];
                 if (fl & HAS_PREV) push_terminal(recs, ld_packed(recs.state1, i), -old_label * alpha / F);
             }
+            const int32_t final_score = score;
             if (over) {
                 lm |= 1u << 11;
                 count_finished(&ws, b, score, overflow);
@@ -478,6 +527,7 @@ __global__ __launch_bounds__(WG) void k_td_play(uint4* boards, int32_t* scores, 
                     fl |= DONE;
                 }
             }
+            if (i < lg.lanes) log_step(lg, i, lm, moved, over, final_score, over && auto_reset, b);
             st_board(boards, i, b);
             st_rng(rng, i, g);
             scores[i] = score;
@@ -807,6 +857,7 @@ struct g2048_ctx {
     float* qdw = nullptr;
     uint32_t* qcount = nullptr;         // [2]: this step's / next step's queue length
     uint16_t* last_move = nullptr;      // what every lane did in the latest TD step (g2048_get_last_move)
+    GameLog log = {0, 0, nullptr, nullptr, nullptr};
     uint32_t step_parity = 0;
     float *w = nullptr, *w0 = nullptr, *delta = nullptr;
     Stats* stats = nullptr;
@@ -1151,7 +1202,7 @@ int launch_td_step(g2048_ctx* c, float alpha, hipEvent_t ev = nullptr) {
     recs.qcount = c->qcount + c->step_parity;
     recs.qcount_next = c->qcount + (c->step_parity ^ 1u);
     BY_N(c, (k_td_play<N><<<grid_for(B), WG, 0, c->stream>>>(c->boards, c->scores, c->rng, pn, c->label, c->flags, B, c->w, alpha, recs,
-                                                             c->auto_reset, c->stats, c->last_move)));
+                                                             c->auto_reset, c->stats, c->last_move, c->log)));
     if (ev) (void)hipEventRecord(ev, c->stream);
     if (c->update_mode == 1) {
         if (c->steps_since_plan >= c->replan_every)
@@ -1237,7 +1288,7 @@ int g2048_destroy(g2048_ctx* c) {
     if (!c) return G2048_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void* bufs[] = {c->boards, c->scores, c->rng, c->prev[0], c->prev[1], c->label, c->flags, c->dw1, c->qstate,
+    void* bufs[] = {c->log.moves, c->log.start, c->log.meta, c->boards, c->scores, c->rng, c->prev[0], c->prev[1], c->label, c->flags, c->dw1, c->qstate,
                     c->qdw,    c->qcount, c->last_move, c->w,      c->w0,  c->delta,   c->stats,   c->scratch, c->slices, c->hits, c->D};
     for (void* p : bufs)
         if (p && (p != (void*)c->w || c->owns_table)) (void)hipFree(p);
@@ -1388,6 +1439,7 @@ int g2048_reset(g2048_ctx* c) {
     if (!c) return G2048_ERR_ARG;
     if (int rc = bind(c)) return rc;
     k_new_games<<<grid_for(c->B), WG, 0, c->stream>>>(c->boards, c->scores, c->rng, c->label, c->flags, c->B);
+    if (c->log.lanes) k_log_init<<<grid_for(c->log.lanes), WG, 0, c->stream>>>(c->log, c->boards, c->flags);
     return launched(c, "k_new_games");
 }
 
@@ -1639,6 +1691,43 @@ int g2048_get_last_move(g2048_ctx* c, uint16_t* out) {
     if (!c || !out) return c ? fail(c, G2048_ERR_ARG, "null buffer") : G2048_ERR_ARG;
     if (int rc = bind(c)) return rc;
     return d2h(c, out, c->last_move, (size_t)c->B * 2);
+}
+
+int g2048_log_enable(g2048_ctx* c, uint32_t lanes, uint32_t capacity) {
+    if (!c) return G2048_ERR_ARG;
+    NEED(c, lanes <= c->B && capacity <= (1u << 20) && (lanes == 0) == (capacity == 0), "bad log geometry");
+    if (int rc = bind(c)) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->log.moves) (void)hipFree(c->log.moves);
+    if (c->log.start) (void)hipFree(c->log.start);
+    if (c->log.meta) (void)hipFree(c->log.meta);
+    c->log = GameLog{0, 0, nullptr, nullptr, nullptr};
+    if (lanes == 0) return G2048_OK;
+    int rc;
+    if ((rc = dalloc(c, &c->log.moves, (size_t)lanes * 2 * capacity)) || (rc = dalloc(c, &c->log.start, (size_t)lanes * 2)) ||
+        (rc = dalloc(c, &c->log.meta, (size_t)lanes * 8)))
+        return rc;
+    c->log.lanes = lanes;
+    c->log.capacity = capacity;
+    k_log_init<<<grid_for(lanes), WG, 0, c->stream>>>(c->log, c->boards, c->flags);
+    return launched(c, "k_log_init");
+}
+
+int g2048_log_meta(g2048_ctx* c, uint32_t* out) {
+    if (!c || !out) return c ? fail(c, G2048_ERR_ARG, "null buffer") : G2048_ERR_ARG;
+    if (!c->log.lanes) return fail(c, G2048_ERR_STATE, "game log is not enabled");
+    if (int rc = bind(c)) return rc;
+    return d2h(c, out, c->log.meta, (size_t)c->log.lanes * 8 * 4);
+}
+
+int g2048_log_game(g2048_ctx* c, uint32_t lane, uint32_t slot, uint16_t* moves, uint8_t* start) {
+    if (!c || !moves || !start) return c ? fail(c, G2048_ERR_ARG, "null buffer") : G2048_ERR_ARG;
+    if (!c->log.lanes) return fail(c, G2048_ERR_STATE, "game log is not enabled");
+    NEED(c, lane < c->log.lanes && slot < 2, "bad lane / slot");
+    if (int rc = bind(c)) return rc;
+    int rc;
+    if ((rc = d2h(c, moves, c->log.moves + ((size_t)lane * 2 + slot) * c->log.capacity, (size_t)c->log.capacity * 2))) return rc;
+    return d2h(c, start, c->log.start + (size_t)lane * 2 + slot, 16);
 }
 
 int g2048_stats_get(g2048_ctx* c, g2048_stats* out) {

@@ -205,6 +205,25 @@ class Engine:
         self._c(self.lib.g2048_get_last_move(self.ctx, _buf(out)))
         return out
 
+    def log_enable(self, lanes, capacity):
+        """Keep the moves / tiles of every game of the first `lanes` lanes (up to `capacity` moves each)."""
+        self._log_geometry = (int(lanes), int(capacity))
+        self._c(self.lib.g2048_log_enable(self.ctx, int(lanes), int(capacity)))
+
+    def log_meta(self):
+        lanes, _ = self._log_geometry
+        out = np.empty((lanes, 8), np.uint32)
+        self._c(self.lib.g2048_log_meta(self.ctx, _buf(out)))
+        return out
+
+    def log_game(self, lane, slot):
+        """(moves uint16[capacity], start uint8[4,4]) of one recorded game."""
+        _, cap = self._log_geometry
+        moves = np.empty(cap, np.uint16)
+        start = np.empty((4, 4), np.uint8)
+        self._c(self.lib.g2048_log_game(self.ctx, int(lane), int(slot), _buf(moves), _buf(start)))
+        return moves, start
+
     def set_update_mode(self, mode):
         """1 = LDS-owner update kernel (default), 0 = global fp32 atomics."""
         self._c(self.lib.g2048_set_update_mode(self.ctx, int(mode)))

@@ -132,6 +132,14 @@ int g2048_td_steps_profiled(g2048_ctx* ctx, float alpha, uint32_t nsteps, float*
  * (r_learning.py:244, game_logic.py:121): bits 0-1 direction, bit 2 a move was made, bits 4-7 cell (4*r + c) of
  * the new tile, bits 8-9 the new tile (1 or 2), bit 10 a tile was placed, bit 11 the game ended on this step. */
 int g2048_get_last_move(g2048_ctx* ctx, uint16_t* out /* [B] */);
+/* Per-lane game records for the first `lanes` lanes (Game.moves / Game.tiles / starting_position, game_logic.py:55-66):
+ * every TD step appends the lane's g2048_get_last_move word; two slots per lane, so the game that just ended stays
+ * readable while the next one is written.  capacity = moves kept per game.  (0, 0) turns it off.
+ * meta: [lanes][8] = slot in use, moves so far, games finished, length0, score0, length1, score1, flags
+ * (bit s: slot s did not start at move 0; bit 2+s: slot s has more moves than `capacity`). */
+int g2048_log_enable(g2048_ctx* ctx, uint32_t lanes, uint32_t capacity);
+int g2048_log_meta(g2048_ctx* ctx, uint32_t* meta /* [lanes][8] */);
+int g2048_log_game(g2048_ctx* ctx, uint32_t lane, uint32_t slot, uint16_t* moves /* [capacity] */, uint8_t* start /* [16] */);
 int g2048_stats_get(g2048_ctx* ctx, g2048_stats* out);
 int g2048_stats_reset(g2048_ctx* ctx);
 

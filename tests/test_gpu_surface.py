@@ -136,6 +136,39 @@ def test_batched_training_learns(api):
     early, late = np.mean(hist[:3]), np.mean(hist[-3:])
     assert late > 2.0 * early, (early, late)
     assert any('average over last 1000 episodes' in str(ln) for ln in logs)
+    # the best game of the watched lanes is kept as a replayable Game, like the reference's top_game
+    top = agent.top_game
+    assert top is not None and top.game_over(top.row) and top.odometer == len(top.tiles) == len(top.moves) - 1
+    chain = top.replay(verbose=False)
+    assert np.array_equal(chain[top.odometer][0], top.row) and chain[top.odometer][1] == top.score
+    assert top.score <= agent.top_score
+
+
+def test_device_game_records(api):
+    """g2048_log_*: every game of a watched lane replays from its record to the recorded score; the unwatched lanes
+    are unaffected."""
+    import importlib
+    pkg = importlib.import_module('2048_amd')
+    eng = pkg.Engine(512, n=2, seed=3)
+    eng.init_weights(seed=1, scale=0.01)
+    eng.log_enable(64, 4096)
+    finished = 0
+    agent = api.QAgent(name='t', storage='local', console='local', n=2, with_weights=False)
+    seen = np.zeros(64, np.uint32)
+    for _ in range(40):
+        eng.td_steps(1e-4, 50)
+        meta = eng.log_meta()
+        for lane in np.nonzero(meta[:, 2] != seen)[0][:3]:
+            slot = int(meta[lane, 0]) ^ 1
+            length, score = int(meta[lane, 3 + 2 * slot]), int(meta[lane, 4 + 2 * slot])
+            if meta[lane, 2] - seen[lane] > 1 or not length:
+                continue                                       # two games ended in one window: the older one is gone
+            game = agent._game_from_log(eng, int(lane), slot, length, score)      # asserts the replayed score
+            assert game.odometer == length and game.game_over(game.row)
+            finished += 1
+        seen[:] = meta[:, 2]
+    assert finished >= 20
+    eng.close()
 
 
 def test_batched_look_forward_matches_the_reference_recursion(api):
