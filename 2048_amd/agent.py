@@ -7,13 +7,16 @@ Added keyword arguments: `batch` (concurrent episodes used by train_run / trial;
 time), `seed`, `device`.
 
 Batched TD (batch > 1) is synchronous: in one board-step every lane chooses with the same table, then all
-(state, dw) records are added.  One slot can receive the adds of all 8 images of every lane in the same step, so
-the per-game learning rate is divided accordingly: alpha_device = alpha * num_feat / (8 * batch)   (DESIGN.md).
+(state, dw) records are applied.  `rule` says how:
+  'mean' (default for batch > 1): a slot moves by the MEAN of the dw that target it in the step, with the reference's
+         alpha unchanged — stable at any batch size and the rule that learns (n = 4, 65 536 lanes: mean score 50 000,
+         2048 in 93 % of games after 45 s of training);
+  'sum'  the reference's arithmetic (every dw is added): one slot can receive the adds of all 8 images of every lane
+         in the same step, so alpha is divided accordingly: alpha_device = alpha * num_feat / (8 * batch).
+Batch 1 always uses 'sum' with the reference's alpha and reproduces the reference's trajectories.
 """
 from .game import *  # noqa: F401,F403  (r_learning.py:3 star-imports game_logic the same way)
 from .game import Game, np, pickle, time, deque, load_s3, save_s3, Logger, AGENT_PANE, RUNNING, dash_intervals
-
-import os
 
 from .engine import Engine, NUM_FEAT, feature_layout
 
@@ -81,7 +84,8 @@ class QAgent:
     parameter_shape = {2: (24, 16 ** 2), 3: (52, 16 ** 3), 4: (17, 16 ** 4), 5: (21, 16 ** 5), 6: (33, 0)}     # :88
 
     def __init__(self, name='agent', config_file=None, storage='s3', console='web', log_file=None, n=4, alpha=0.25,
-                 decay=0.75, decay_step=10000, low_alpha_limit=0.01, with_weights=True, batch=1, seed=2048, device=0):
+                 decay=0.75, decay_step=10000, low_alpha_limit=0.01, with_weights=True, batch=1, seed=2048, device=0,
+                 rule=None):
         # basic params (r_learning.py:93-99)
         self.name = name
         self.file = name + '.pkl'
@@ -108,6 +112,7 @@ class QAgent:
         self.top_tile = 10
         # device side
         self.batch, self.seed, self.device = int(batch), int(seed), int(device)
+        self.rule = rule or ('mean' if self.batch > 1 else 'sum')
         self._engine = self._solo = None
         self._pending_weights = None
         self.weight_signature = None
@@ -124,6 +129,8 @@ class QAgent:
         """The training batch (owns the weight table)."""
         if self._engine is None:
             self._engine = Engine(self.batch, n=self.n, seed=self.seed, device=self.device)
+            if self.batch > 1 and self.rule == 'mean':
+                self._engine.set_update_rule(1)
             if self._pending_weights is not None:
                 self._engine.set_weights(self._pending_weights)
                 self._pending_weights = None
@@ -188,6 +195,7 @@ class QAgent:
         self.__dict__.setdefault('batch', 1)
         self.__dict__.setdefault('seed', 2048)
         self.__dict__.setdefault('device', 0)
+        self.__dict__.setdefault('rule', 'mean' if self.batch > 1 else 'sum')
         self._engine = self._solo = self._pending_weights = None
         self.print = print
         self.features = QAgent.feature_functions[self.n]
@@ -355,8 +363,9 @@ class QAgent:
     def device_alpha(self, lanes=None):
         """The batch rule: alpha for g2048_td_steps when `lanes` episodes learn concurrently."""
         lanes = self.batch if lanes is None else lanes
-        mult = float(os.environ.get('G2048_ALPHA_MULT', '1'))          # (experiments with the batch rule)
-        return self.alpha if lanes == 1 else mult * self.alpha * self.num_feat / (8.0 * lanes)
+        if lanes == 1 or self.rule == 'mean':
+            return self.alpha
+        return self.alpha * self.num_feat / (8.0 * lanes)
 
     WATCHED_LANES, LOG_CAPACITY = 1024, 16384
 

@@ -402,6 +402,7 @@ struct TdRecs {
     float* qdw;             // [B]
     uint32_t* qcount;       // length of this step's queue
     uint32_t* qcount_next;  // next step's counter, zeroed by k_td_play
+    uint32_t unit;          // 1: every record counts as dw = 1 (the counting pass of the per-slot mean rule)
 };
 
 __device__ __forceinline__ void push_terminal(const TdRecs& r, const Packed& state, float dw) {
@@ -677,6 +678,7 @@ __device__ __forceinline__ void own_run(float* acc, const Slice& s, const TdRecs
                 const uint32_t rr = ok ? r : end - 1;
                 st[u] = recs.state1[rr];
                 dw[u] = ok ? recs.dw1[rr] : 0.0f;
+                if (recs.unit) dw[u] = dw[u] != 0.0f ? 1.0f : 0.0f;
             }
 #pragma unroll
             for (int u = 0; u < OWN_UNROLL; ++u) own_accum<N, F0, FC, FB>(unpack4(st[u]), dw[u], dw[u] != 0.0f, acc, s, nhit, D, fb_hits);
@@ -689,7 +691,7 @@ __device__ __forceinline__ void own_run(float* acc, const Slice& s, const TdRecs
             const uint32_t r = base0 + threadIdx.x;
             const bool ok = r < end;
             const uint32_t rr = ok ? r : end - 1;
-            own_accum<N, F0, FC, FB>(ld_packed(recs.qstate, rr), recs.qdw[rr], ok, acc, s, nhit, D, fb_hits);
+            own_accum<N, F0, FC, FB>(ld_packed(recs.qstate, rr), recs.unit ? 1.0f : recs.qdw[rr], ok, acc, s, nhit, D, fb_hits);
         }
     }
     // load statistics for the planner: one counter bump per wave
@@ -756,6 +758,35 @@ __global__ __launch_bounds__(WG) void k_apply_orbits(float* w, float* D, OrbitTa
     for (uint32_t m = 0; m < oi.nmem; ++m) w[oi.off[m] + permute_digits(k, oi.perm[m], oi.digits, oi.radix)] += v;
 }
 
+// Per-slot mean rule (g2048_set_update_rule): S = sum of the dw that target a slot, C = how many did; the slot moves
+// by S / C.  S and C come from two runs of the same accumulation (the second with dw = 1).
+__global__ __launch_bounds__(WG) void k_apply_orbits_mean(float* w, float* S, float* C, OrbitTable t) {
+    const uint32_t K = blockIdx.x * WG + threadIdx.x;
+    if (K >= t.total) return;
+    const float cnt = C[K];
+    if (cnt == 0.0f) return;
+    const float v = S[K] / cnt;
+    S[K] = 0.0f;
+    C[K] = 0.0f;
+    uint32_t o = 0;
+#pragma unroll
+    for (uint32_t j = 1; j < MAX_ORBITS; ++j)
+        if (j < t.count && K >= t.o[j].base) o = j;
+    const OrbitInfo& oi = t.o[o];
+    const uint32_t k = K - oi.base;
+    for (uint32_t m = 0; m < oi.nmem; ++m) w[oi.off[m] + permute_digits(k, oi.perm[m], oi.digits, oi.radix)] += v;
+}
+
+__global__ __launch_bounds__(WG) void k_apply_flat_mean(float* w, float* S, float* C, uint32_t slots) {
+    const uint32_t K = blockIdx.x * WG + threadIdx.x;
+    if (K >= slots) return;
+    const float cnt = C[K];
+    if (cnt == 0.0f) return;
+    w[K] += S[K] / cnt;
+    S[K] = 0.0f;
+    C[K] = 0.0f;
+}
+
 // n = 6: the twelve 14^6-slot tables (361 MB) do not fit in LDS, so their adds end as global atomics — but (1) through
 // the orbits: the 12 features fall into two orbits (8 corner blocks, 4 middle blocks) whose representatives are
 // features 21 and 22, so a record costs 2 x 8 = 16 adds into D instead of 96 into the table; and (2) through a
@@ -796,6 +827,7 @@ __global__ __launch_bounds__(OWN_WG) void k_td_update_tail(float* D, TdRecs recs
             dw = recs.qdw[r - B];
             p = ld_packed(recs.qstate, r - B);
         }
+        if (recs.unit) dw = 1.0f;
         uint32_t s[F];
         feature_slots<N>(d4_image(p, g), s);
         cached_add(keys, vals, D, dbaseA + (s[21] - feature_offset(N, 21)), dw);
@@ -867,7 +899,9 @@ struct g2048_ctx {
     uint32_t n_chunks = 0;
     uint32_t steps_since_plan = 0, replan_every = 8;     // the board distribution drifts with the games' age: follow it closely
     std::vector<double> load;           // smoothed adds per step per chunk
-    float* D = nullptr;                 // per-orbit delta tables (n >= 4)
+    float* D = nullptr;                 // per-orbit delta tables (n >= 4; mean rule: also the sums for n = 2, 3)
+    float* Dcnt = nullptr;              // mean rule: how many adds each slot of D received
+    int update_rule = 0;                // 0: add every dw (QAgent.update), 1: per-slot mean
     OrbitTable orbits = {};
     int update_mode = 1;                // 1: LDS-owner update (default), 0: global fp32 atomics
     bool owns_table = true;             // false: `w` belongs to the parent context (g2048_create_shared)
@@ -1201,6 +1235,7 @@ int launch_td_step(g2048_ctx* c, float alpha, hipEvent_t ev = nullptr) {
     recs.qdw = c->qdw;
     recs.qcount = c->qcount + c->step_parity;
     recs.qcount_next = c->qcount + (c->step_parity ^ 1u);
+    recs.unit = 0;
     BY_N(c, (k_td_play<N><<<grid_for(B), WG, 0, c->stream>>>(c->boards, c->scores, c->rng, pn, c->label, c->flags, B, c->w, alpha, recs,
                                                              c->auto_reset, c->stats, c->last_move, c->log)));
     if (ev) (void)hipEventRecord(ev, c->stream);
@@ -1208,11 +1243,25 @@ int launch_td_step(g2048_ctx* c, float alpha, hipEvent_t ev = nullptr) {
         if (c->steps_since_plan >= c->replan_every)
             if (int rc = replan(c)) return rc;
         ++c->steps_since_plan;
-        float* dst = c->n >= 4 ? c->D : c->w;
+        const uint32_t tail_grid = B >= (1u << 16) ? 512 : 16;
+        recs.unit = 0;
+        if (c->update_rule == 1) {      // counting pass: the same accumulation with dw = 1, into Dcnt
+            TdRecs ones = recs;
+            ones.unit = 1;
+            BY_N(c, (k_td_update_owner<N><<<c->n_slices, OWN_WG, 0, c->stream>>>(c->Dcnt, ones, B, c->slices, c->hits)));
+            if (c->n == 6) k_td_update_tail<6><<<tail_grid, OWN_WG, 0, c->stream>>>(c->Dcnt, ones, B, c->orbits.o[6].base, c->orbits.o[7].base);
+        }
+        float* dst = (c->n >= 4 || c->update_rule == 1) ? c->D : c->w;
         BY_N(c, (k_td_update_owner<N><<<c->n_slices, OWN_WG, 0, c->stream>>>(dst, recs, B, c->slices, c->hits)));
-        if (c->n == 6)
-            k_td_update_tail<6><<<B >= (1u << 16) ? 512 : 16, OWN_WG, 0, c->stream>>>(c->D, recs, B, c->orbits.o[6].base, c->orbits.o[7].base);
-        if (c->n >= 4) k_apply_orbits<<<grid_for(c->orbits.total), WG, 0, c->stream>>>(c->w, c->D, c->orbits);
+        if (c->n == 6) k_td_update_tail<6><<<tail_grid, OWN_WG, 0, c->stream>>>(c->D, recs, B, c->orbits.o[6].base, c->orbits.o[7].base);
+        if (c->update_rule == 1) {
+            if (c->n >= 4)
+                k_apply_orbits_mean<<<grid_for(c->orbits.total), WG, 0, c->stream>>>(c->w, c->D, c->Dcnt, c->orbits);
+            else
+                k_apply_flat_mean<<<grid_for(c->slots), WG, 0, c->stream>>>(c->w, c->D, c->Dcnt, (uint32_t)c->slots);
+        } else if (c->n >= 4) {
+            k_apply_orbits<<<grid_for(c->orbits.total), WG, 0, c->stream>>>(c->w, c->D, c->orbits);
+        }
     } else {
         BY_N(c, (k_td_update<N><<<grid_for((uint64_t)B * 16), WG, 0, c->stream>>>(c->w, recs, B)));
     }
@@ -1289,7 +1338,7 @@ int g2048_destroy(g2048_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* bufs[] = {c->log.moves, c->log.start, c->log.meta, c->boards, c->scores, c->rng, c->prev[0], c->prev[1], c->label, c->flags, c->dw1, c->qstate,
-                    c->qdw,    c->qcount, c->last_move, c->w,      c->w0,  c->delta,   c->stats,   c->scratch, c->slices, c->hits, c->D};
+                    c->qdw,    c->qcount, c->last_move, c->w,      c->w0,  c->delta,   c->stats,   c->scratch, c->slices, c->hits, c->D, c->Dcnt};
     for (void* p : bufs)
         if (p && (p != (void*)c->w || c->owns_table)) (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -1657,7 +1706,30 @@ int g2048_td_steps(g2048_ctx* c, float alpha, uint32_t nsteps) {
 int g2048_set_update_mode(g2048_ctx* c, int mode) {
     if (!c) return G2048_ERR_ARG;
     NEED(c, mode == 0 || mode == 1, "update mode must be 0 (global atomics) or 1 (LDS-owner)");
+    NEED(c, mode == 1 || c->update_rule == 0, "the per-slot mean rule needs update mode 1");
     c->update_mode = mode;
+    return G2048_OK;
+}
+
+int g2048_set_update_rule(g2048_ctx* c, int rule) {
+    if (!c) return G2048_ERR_ARG;
+    NEED_TABLE(c);
+    NEED(c, rule == 0 || rule == 1, "update rule must be 0 (add every dw) or 1 (per-slot mean)");
+    if (rule == 1) {
+        NEED(c, c->update_mode == 1, "the per-slot mean rule needs the LDS-owner update (update mode 1)");
+        if (int rc = bind(c)) return rc;
+        const size_t count = c->n >= 4 ? c->orbits.total : c->slots;
+        int rc;
+        if (!c->D) {
+            if ((rc = dalloc(c, &c->D, count))) return rc;
+            HIP_TRY(c, hipMemset(c->D, 0, count * 4));
+        }
+        if (!c->Dcnt) {
+            if ((rc = dalloc(c, &c->Dcnt, count))) return rc;
+            HIP_TRY(c, hipMemset(c->Dcnt, 0, count * 4));
+        }
+    }
+    c->update_rule = rule;
     return G2048_OK;
 }
 

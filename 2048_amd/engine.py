@@ -228,6 +228,10 @@ class Engine:
         """1 = LDS-owner update kernel (default), 0 = global fp32 atomics."""
         self._c(self.lib.g2048_set_update_mode(self.ctx, int(mode)))
 
+    def set_update_rule(self, rule):
+        """0 = add every dw (the reference's update), 1 = per-slot mean of the step's dw."""
+        self._c(self.lib.g2048_set_update_rule(self.ctx, int(rule)))
+
     def stats(self):
         st = _lib.Stats()
         self._c(self.lib.g2048_stats_get(self.ctx, ctypes.byref(st)))

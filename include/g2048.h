@@ -125,6 +125,11 @@ int g2048_td_steps(g2048_ctx* ctx, float alpha, uint32_t nsteps);
 /* how the step's records are added to the table: 1 (default) = LDS-owner kernel (workgroups own 128 KiB table
  * slices in LDS, no global atomics for n <= 5), 0 = one global fp32 atomic per slot.  Same sums either way. */
 int g2048_set_update_mode(g2048_ctx* ctx, int mode);
+/* what a step's records do to a slot: 0 (default) = every dw is added, as QAgent.update does (r_learning.py:207-214);
+ * 1 = per-slot mean: a slot that S of the step's dw target, C in number, moves by S / C.  Rule 1 is an extension for
+ * large synchronous batches (with rule 0 the step size must shrink with the batch); it is not the
+ * reference's arithmetic even at batch 1 (a symmetric board hits one slot several times). */
+int g2048_set_update_rule(g2048_ctx* ctx, int rule);
 /* the same, with HIP events around each of the step's two kernels (synchronises every step): average
  * milliseconds per launch of k_td_play and k_td_update, for the roofline line of bench.py */
 int g2048_td_steps_profiled(g2048_ctx* ctx, float alpha, uint32_t nsteps, float* ms_play, float* ms_update);

@@ -201,13 +201,26 @@ def select(n, weights, boards):
             changed.any(axis=1), vals)
 
 
-def update(n, weights, states, dw):
+def update(n, weights, states, dw, rule='sum'):
     """QAgent.update (r_learning.py:207-214) for a batch of (state, dw) records: weights[slot] += dw for
-    every feature of the 8 symmetric images (coincident slots accumulate).  In place on float64 `weights`."""
+    every feature of the 8 symmetric images (coincident slots accumulate).  In place on float64 `weights`.
+    rule='mean' is NOT the reference: it restates the device's optional per-slot mean rule (a slot targeted by C of
+    the batch's dw, summing to S, moves by S / C; records with dw == 0 do not count), for its parity test."""
     dw = np.asarray(dw, dtype=weights.dtype)
+    if rule == 'sum':
+        for img in d4_images(states):
+            s = slots(n, img)
+            np.add.at(weights, s.ravel(), np.repeat(dw, s.shape[1]))
+        return weights
+    total = np.zeros_like(weights)
+    count = np.zeros_like(weights)
+    live = dw != 0
     for img in d4_images(states):
-        s = slots(n, img)
-        np.add.at(weights, s.ravel(), np.repeat(dw, s.shape[1]))
+        s = slots(n, img)[live]
+        np.add.at(total, s.ravel(), np.repeat(dw[live], s.shape[1]))
+        np.add.at(count, s.ravel(), 1.0)
+    hit = count > 0
+    weights[hit] += total[hit] / count[hit]
     return weights
 
 
@@ -227,7 +240,7 @@ class Lanes:
         self.moves = np.zeros(B, dtype=np.int64)
 
 
-def td_step(n, weights, lanes, alpha, draws):
+def td_step(n, weights, lanes, alpha, draws, rule='sum'):
     """One synchronous board-step for every live lane: the body of the while loop of QAgent.episode
     (r_learning.py:228-246) plus, for lanes whose game ends after the spawn, the terminal update
     (r_learning.py:247-249).  All lanes read the same `weights`; every (state, dw) record of the step is
@@ -264,6 +277,6 @@ def td_step(n, weights, lanes, alpha, draws):
     rec_dw.append(dw2[over])
     lanes.done[idx[over]] = True
     rec_states, rec_dw = np.concatenate(rec_states), np.concatenate(rec_dw)
-    update(n, weights, rec_states, rec_dw)
+    update(n, weights, rec_states, rec_dw, rule)
     return dict(rec_states=rec_states, rec_dw=rec_dw, lanes=idx, action=action, value=value, values4=vals, reward=reward, dw=np.where(hp, dw1, 0.0),
                 over=over, dw_term=np.where(over, dw2, 0.0))

@@ -79,7 +79,8 @@ def test_reference_surface_is_importable_under_its_own_names():
     a = QAgent(name='x', storage='local', console='local', n=4, with_weights=False)
     assert (a.num_feat, a.n, a.alpha, a.decay, a.decay_step, a.low_alpha_limit) == (17, 4, 0.25, 0.75, 10000, 0.01)
     assert a.weights is None and a.weight_signature is None
-    assert abs(QAgent(n=5, with_weights=False, batch=1 << 20).device_alpha() - 0.25 * 21 / (8 * 2 ** 20)) < 1e-12
+    assert abs(QAgent(n=5, with_weights=False, batch=1 << 20, rule='sum').device_alpha() - 0.25 * 21 / (8 * 2 ** 20)) < 1e-12
+    assert QAgent(n=5, with_weights=False, batch=1 << 20).device_alpha() == 0.25 and QAgent(n=5, with_weights=False).rule == 'sum'
 
 
 def test_shard_lanes_partitions_exactly():

@@ -291,6 +291,19 @@ def test_td_steps_batch_vs_oracle(n, mode):
     eng.close()
 
 
+@pytest.mark.parametrize('n', [2, 3, 4, 5, 6])
+def test_td_mean_rule_vs_oracle(n):
+    """The optional per-slot mean rule (g2048_set_update_rule(1)) against its restatement in the oracle."""
+    B = 4096
+    eng = Engine(B, n=n, seed=200 + n)
+    eng.set_auto_reset(False)
+    eng.set_update_rule(1)
+    eng.step_random(30)
+    for t in range(4):
+        helpers.check_td_step(eng, n, formulas.exact_alpha(n), formulas.weights(n, scale=2.0 ** -(4 + t)), rule='mean')
+    eng.close()
+
+
 @pytest.mark.parametrize('mode', [1, 0])
 def test_td_batch_until_all_games_end(mode):
     """256 lanes played to the end with learning on: the per-step check holds through terminal updates and DONE."""

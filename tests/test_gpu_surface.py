@@ -134,7 +134,7 @@ def test_batched_training_learns(api):
     hist = agent.train_history
     assert agent.step >= 60000 and len(hist) >= 10
     early, late = np.mean(hist[:3]), np.mean(hist[-3:])
-    assert late > 2.0 * early, (early, late)
+    assert late > 3.0 * early and late > 5000, (early, late)     # per-slot mean rule: from ~1 000 to well over 5 000
     assert any('average over last 1000 episodes' in str(ln) for ln in logs)
     # the best game of the watched lanes is kept as a replayable Game, like the reference's top_game
     top = agent.top_game

@@ -8,7 +8,8 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else 1 << 16
 episodes = int(sys.argv[3]) if len(sys.argv) > 3 else 5_000_000
 alpha = float(sys.argv[4]) if len(sys.argv) > 4 else 0.25
-agent = QAgent(name=f'a{n}', storage='local', console='local', n=n, alpha=alpha, batch=batch, seed=1, decay_step=episodes // 4)
+rule = os.environ.get('G2048_RULE', 'mean')
+agent = QAgent(name=f'a{n}', storage='local', console='local', n=n, alpha=alpha, batch=batch, seed=1, decay_step=episodes // 4, rule=rule)
 lines = []
 def log(x):
     x = str(x)
