@@ -59,6 +59,27 @@ def cpu_baseline(n, seconds):
                        f'(oracle/ref_scalar.py, NumPy {np.__version__}, host has {os.cpu_count()} logical cores)')
 
 
+def measured_copy_gbps(device):
+    """The box's own device-to-device copy rate (read + write bytes per second) — the practical HBM ceiling next to the
+    8 TB/s datasheet peak."""
+    try:
+        import torch
+        dev = torch.device('cuda', device)
+        a = torch.empty(1 << 28, dtype=torch.uint8, device=dev)        # 256 MiB, beyond the Infinity Cache with its copy
+        b = torch.empty_like(a)
+        for _ in range(2):
+            b.copy_(a)
+        start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        start.record()
+        for _ in range(10):
+            b.copy_(a)
+        stop.record()
+        stop.synchronize()
+        return 2 * a.numel() * 10 / (start.elapsed_time(stop) * 1e-3) / 1e9
+    except Exception:
+        return None
+
+
 def side_workload(pkg, args):
     """BASELINE configs 2 and 3 (parity-test cases, measured for DESIGN.md; not the bench metric)."""
     if args.workload == 'env':
@@ -107,6 +128,9 @@ def main():
     ap.add_argument('--workload', default='td', choices=['td', 'env', 'eval'],
                     help='td = BASELINE config 4 (the metric); env = config 2 (65 536 lanes, env step only); eval = config 3 '
                          '(262 144 lanes, n=3 evaluate + greedy select); env/eval print a reduced JSON line')
+    ap.add_argument('--rule', default='sum', choices=['sum', 'mean'],
+                    help="how a step's records are applied: 'sum' = the reference's arithmetic (the metric); 'mean' = per-slot "
+                         "mean (what QAgent uses for batched training; a second accumulation pass)")
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse on one GPU)')
     args = ap.parse_args()
 
@@ -138,6 +162,9 @@ def main():
     # batch rule: every lane adds its delta in the same step and one slot can be hit by all 8 images of every
     # lane, so the reference's per-game alpha is divided by 8 * (concurrent episodes) / num_feat
     alpha = args.alpha * NUM_FEAT[n] / (8.0 * B * world)
+    if args.rule == 'mean':
+        eng.set_update_rule(1)
+        alpha = args.alpha
     sync = par.DeltaSync(eng, dist) if world > 1 else None
 
     def run(steps):
@@ -198,13 +225,14 @@ def main():
             'dtype': 'u8 boards / int32 scores / f32 weights', 'data': 'synthetic',
             'config': {'workload': f'BASELINE config 4: full TD(0) loop, {n}-tuple table ({eng.slots * 4} B), '
                                    f'{B} concurrent episodes per GPU, auto-reset',
-                       'batch_per_gpu': B, 'n_tuple': n, 'alpha_effective': alpha,
+                       'batch_per_gpu': B, 'n_tuple': n, 'alpha_effective': alpha, 'update_rule': args.rule,
                        'parallelism': f'episodes sharded over {world} GPU(s)' + (f', weight-delta all-reduce every {args.epoch} steps' if world > 1 else '')},
             'roofline': {'bound': 'hbm', 'kernel': 'k_td_update_owner' if dominant == 'k_td_update' else dominant, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          'algorithmic_bytes_per_launch': dom_bytes, 'ms_per_launch': dom_ms,
                          'ms_k_td_play': ms_play, 'ms_k_td_update': ms_update,
-                         'whole_step_algorithmic_GBps': (by_play + by_update) * B / (dt / K) / 1e9},
+                         'whole_step_algorithmic_GBps': (by_play + by_update) * B / (dt / K) / 1e9,
+                         'measured_copy_GBps': measured_copy_gbps(local_rank)},
             'hip_event_ms_per_step': ev_ms / K,
             'episodes_finished': st['episodes'],
             'mean_score': st['score_sum'] / max(1, st['episodes']),
