@@ -75,6 +75,49 @@ def f_6(x):
     return _features(6, x)
 
 
+class _Stopper:
+    """The cooperative stop protocol of the Dash workers (r_learning.py:284-290): the pane's current worker id and the
+    browser heartbeat."""
+
+    def __init__(self, stopper, key='a'):
+        self.parent, self.me = (stopper['parent'], stopper[key]) if stopper else (None, None)
+        self.mark = time.time()
+
+    def poll(self):
+        if self.parent is None:
+            return 'go'
+        if AGENT_PANE[self.parent]['id'] != self.me:
+            return 'stop'
+        self.mark = check_thread(self.parent, self.mark)
+        return 'go' if self.mark else 'abandoned'
+
+
+class _Window:
+    """Statistics of the games since the last 1000-episode report (r_learning.py:279-282, 297-309)."""
+
+    def __init__(self):
+        self.scores, self.last100 = [], deque(maxlen=100)
+        self.reached = [0] * 7                  # games whose largest tile was 2^10 .. 2^16
+        self.best, self.since = None, time.time()
+
+    def add(self, game, top_tile):
+        """Returns True if `game` is the best of the window so far."""
+        self.scores.append(game.score)
+        self.last100.append(game.score)
+        if top_tile >= 10:
+            self.reached[min(top_tile, 16) - 10] += 1
+        if self.best is None or game.score > self.best.score:
+            self.best = game
+            return True
+        return False
+
+    def ma100(self):
+        return int(np.mean(self.last100))
+
+    def mean(self):
+        return np.mean(self.scores)
+
+
 GROUPS = {2: (24,), 3: (52,), 4: (17,), 5: (17, 4), 6: (17, 4, 12)}       # weight_signature, r_learning.py:136-149
 
 
@@ -86,30 +129,22 @@ class QAgent:
     def __init__(self, name='agent', config_file=None, storage='s3', console='web', log_file=None, n=4, alpha=0.25,
                  decay=0.75, decay_step=10000, low_alpha_limit=0.01, with_weights=True, batch=1, seed=2048, device=0,
                  rule=None):
-        # basic params (r_learning.py:93-99)
-        self.name = name
-        self.file = name + '.pkl'
-        self.game_file = 'best_of_' + self.file
-        self.s3 = (storage == 's3')
-        self.log_file = log_file
-        self.print = print if (console == 'local' or log_file is None) else Logger(log_file=log_file).add
-        # params from config file or init/defaults (r_learning.py:101-110)
-        config = (load_s3(config_file) or {}) if config_file else {}
-        self.n = config.get('n', n)
-        self.alpha = config.get('alpha', alpha)
-        self.decay = config.get('decay', decay)
-        self.decay_step = config.get('decay_step', decay_step)
-        self.low_alpha_limit = config.get('low_alpha_limit', low_alpha_limit)
-        # derived params (r_learning.py:112-114)
-        self.num_feat, self.size_feat = QAgent.parameter_shape[self.n]
+        # identity and I/O (r_learning.py:93-99)
+        self.name, self.file, self.game_file = name, name + '.pkl', 'best_of_' + name + '.pkl'
+        self.s3, self.log_file = storage == 's3', log_file
+        to_console = console == 'local' or log_file is None
+        self.print = print if to_console else Logger(log_file=log_file).add
+        # hyper-parameters: a stored JSON config wins over the arguments (r_learning.py:101-110)
+        stored = (load_s3(config_file) or {}) if config_file else {}
+        given = dict(n=n, alpha=alpha, decay=decay, decay_step=decay_step, low_alpha_limit=low_alpha_limit)
+        for key, value in given.items():
+            setattr(self, key, stored.get(key, value))
+        self.num_feat, self.size_feat = QAgent.parameter_shape[self.n]      # r_learning.py:112-114
         self.features = QAgent.feature_functions[self.n]
-        # operational params (r_learning.py:116-122)
-        self.step = 0
-        self.top_game = None
-        self.top_score = 0
-        self.train_history = []
+        # training state (r_learning.py:116-122)
+        self.step, self.top_score, self.top_tile = 0, 0, 10
+        self.top_game, self.train_history = None, []
         self.next_decay = self.decay_step
-        self.top_tile = 10
         # device side
         self.batch, self.seed, self.device = int(batch), int(seed), int(device)
         self.rule = rule or ('mean' if self.batch > 1 else 'sum')
@@ -288,48 +323,38 @@ class QAgent:
             self.weights = [row for g in groups for row in np.asarray(g)]
         if self.batch > 1:
             return self._train_run_batched(num_eps, saving, stopper)
-        if stopper:
-            parent, this_thread = stopper['parent'], stopper['a']
-        av1000, ma100 = [], deque(maxlen=100)
-        reached = [0] * 7
-        best_of_1000 = None
-        global_start = start = benchmark_time = time.time()
+        watch = _Stopper(stopper)
+        window = _Window()
+        began = time.time()
         self.print(f'Agent {self.name} training session started, current step = {self.step}')
         self.print('Agent will be saved every 1000 episodes and on STOP command')
-        for i in range(self.step + 1, self.step + num_eps + 2):
-            if stopper:
-                if AGENT_PANE[parent]['id'] != this_thread:
-                    break
-                benchmark_time = check_thread(parent, benchmark_time)
-                if not benchmark_time:
-                    return
+        first = self.step + 1
+        for i in range(first, first + num_eps + 1):                  # (the reference also plays num_eps + 1 games, :284)
+            verdict = watch.poll()
+            if verdict == 'stop':
+                break
+            if verdict == 'abandoned':
+                return
             if self.step > self.next_decay and self.alpha > self.low_alpha_limit:
                 self.decay_alpha()
             game = self.episode()
-            ma100.append(game.score)
-            av1000.append(game.score)
-            if best_of_1000 is None or game.score > best_of_1000.score:
-                best_of_1000 = game
-                if game.score > self.top_score:
-                    self.top_game, self.top_score = game, game.score
-                    self.print(f'\nnew best game at episode {i}!\n{game}\n')
-                    if saving:
-                        self.save_game(game)
-                        self.print(f'game saved at {self.game_file}')
-            max_tile = int(np.max(game.row))
-            if max_tile >= 10:
-                reached[min(max_tile, 16) - 10] += 1
-            if max_tile > self.top_tile:                             # new maximum tile: decay (r_learning.py:311-313)
-                self.top_tile = max_tile
+            top = int(np.max(game.row))
+            if window.add(game, top) and game.score > self.top_score:       # best of this window and of the agent
+                self.top_game, self.top_score = game, game.score
+                self.print(f'\nnew best game at episode {i}!\n{game}\n')
+                if saving:
+                    self.save_game(game)
+                    self.print(f'game saved at {self.game_file}')
+            if top > self.top_tile:                                  # a new largest tile also decays alpha (r_learning.py:311-313)
+                self.top_tile = top
                 self.decay_alpha()
             if i % 100 == 0:
-                ma = int(np.mean(ma100))
-                self.train_history.append(ma)
-                self.print(f'episode {i}: score {game.score} reached {1 << max_tile} ma_100 = {ma}')
+                self.train_history.append(window.ma100())
+                self.print(f'episode {i}: score {game.score} reached {1 << top} ma_100 = {self.train_history[-1]}')
             if i % 1000 == 0:
-                self._report_1000(i, np.mean(av1000), reached, best_of_1000, time.time() - start, saving)
-                start, av1000, reached, best_of_1000 = time.time(), [], [0] * 7, None
-        self._finish(global_start, saving)
+                self._report_1000(i, window.mean(), window.reached, window.best, time.time() - window.since, saving)
+                window = _Window()
+        self._finish(began, saving)
 
     def _report_1000(self, i, average, reached, best, seconds, saving):     # r_learning.py:318-341
         self.print('\n------')
@@ -461,58 +486,41 @@ class QAgent:
     @staticmethod
     def trial(estimator=None, agent_file=None, limit_tile=0, num=20, game_init=None, depth=0, width=1, since_empty=6,
               storage='s3', console='local', log_file=None, game_file=None, verbose=False, stopper=None):
+        """`num` games played with `estimator` (or a stored agent), then the summary the reference prints
+        (r_learning.py:348-406).  A device agent at depth 0 plays all games at once on the GPU."""
         display = print if console == 'local' else Logger(log_file=log_file).add
-        if stopper:
-            parent, this_thread = stopper['parent'], stopper['a']
         if agent_file:
             display(f'Loading Agent from {agent_file} ...')
             agent = QAgent.load_agent(agent_file)
             estimator = agent.evaluate
             display(f'Trial run for {num} games, Agent = {agent.name}\n'
                     f'Looking forward: depth={depth}, width={width}, since_empty={since_empty}')
-        start = benchmark_time = time.time()
+        began = time.time()
         owner = getattr(estimator, '__self__', None)
-        shuffles = Game.counter
-        if isinstance(owner, QAgent) and depth == 0 and not limit_tile and not verbose and not stopper:
-            results, shuffles = owner._trial_batched(num, game_init), 0
+        on_device = isinstance(owner, QAgent) and depth == 0 and not limit_tile and not verbose and not stopper
+        if on_device:
+            results = owner._trial_batched(num, game_init)
             for i, game in enumerate(results):
                 display(f'game {i}, result {game.score}, moves {game.odometer}, achieved {1 << np.max(game.row)}')
         else:
-            results = []
+            watch, results = _Stopper(stopper), []
             for i in range(num):
-                if stopper:
-                    if AGENT_PANE[parent]['id'] != this_thread:
-                        break
-                    benchmark_time = check_thread(parent, benchmark_time)
-                    if not benchmark_time:
-                        return
-                now = time.time()
-                game = Game() if game_init is None else game_init.copy()
+                verdict = watch.poll()
+                if verdict == 'stop':
+                    break
+                if verdict == 'abandoned':
+                    return
+                t0 = time.time()
+                game = game_init.copy() if game_init is not None else Game()
                 game.trial_run(estimator, limit_tile=limit_tile, depth=depth, width=width, since_empty=since_empty,
                                verbose=verbose)
                 display(f'game {i}, result {game.score}, moves {game.odometer}, achieved {1 << np.max(game.row)}, '
-                        f'time = {(time.time() - now):.2f}')
+                        f'time = {(time.time() - t0):.2f}')
                 results.append(game)
-            shuffles = Game.counter
         if not results:
             return
-        average = np.average([v.score for v in results])
-        figures = [(1 << np.max(v.row)) for v in results]
-        total_odo = sum([v.odometer for v in results])
-        results.sort(key=lambda v: v.score, reverse=True)
-
-        def share(limit):
-            return len([0 for v in figures if v >= limit]) / len(figures) * 100
-
-        elapsed = time.time() - start
-        message = '\nBest games:\n' + ''.join(str(v) + '\n\n' for v in results[:3])
-        message += f'average score of {len(results)} runs = {average}\n'
-        for limit in (16384, 8192, 4096, 2048, 1024):
-            message += f'{limit} reached in {share(limit)}%\n'
-        message += f'total time = {round(elapsed, 2)}\naverage time per move = {round(elapsed / max(1, total_odo) * 1000, 2)} ms\n'
-        if shuffles:
-            message += f'total number of shuffles = {shuffles}\ntime per shuffle = {round(elapsed / shuffles * 1000, 2)} ms'
-        display(message)
+        results.sort(key=lambda g: g.score, reverse=True)
+        display(QAgent._trial_summary(results, time.time() - began, 0 if on_device else Game.counter))
         if game_file:
             if storage == 's3':
                 save_s3(results[0], game_file)
@@ -520,6 +528,21 @@ class QAgent:
                 results[0].save_game(file=game_file)
             display(f'Best game saved at {game_file}\n------------------------\n')
         return results
+
+    @staticmethod
+    def _trial_summary(results, elapsed, shuffles):
+        """The closing message of QAgent.trial (r_learning.py:378-399): best games, mean score, tile shares, timings."""
+        top_tiles = np.array([1 << int(np.max(g.row)) for g in results])
+        moves = max(1, sum(g.odometer for g in results))
+        lines = ['', 'Best games:'] + [f'{g}\n' for g in results[:3]]
+        lines.append(f'average score of {len(results)} runs = {np.average([g.score for g in results])}')
+        lines += [f'{limit} reached in {(top_tiles >= limit).mean() * 100}%' for limit in (16384, 8192, 4096, 2048, 1024)]
+        lines.append(f'total time = {round(elapsed, 2)}')
+        lines.append(f'average time per move = {round(elapsed / moves * 1000, 2)} ms')
+        if shuffles:
+            lines.append(f'total number of shuffles = {shuffles}')
+            lines.append(f'time per shuffle = {round(elapsed / shuffles * 1000, 2)} ms')
+        return '\n'.join(lines)
 
     def _trial_batched(self, num, game_init=None):
         """`num` greedy games at once on the device (alpha = 0: no records, no learning), each to its end."""

@@ -97,6 +97,20 @@ def test_agent_episode_returns_a_replayable_game(api):
     assert np.abs(after - before).max() > 0                    # it learned something
 
 
+def test_train_run_one_game_at_a_time(api):
+    """batch = 1: the reference's own loop (r_learning.py:269-346) — num_eps + 1 episodes, best-game capture, ma_100 log."""
+    agent = api.QAgent(name='t', storage='local', console='local', n=2, alpha=0.2, seed=6)
+    logs = []
+    agent.print = logs.append
+    agent.train_run(num_eps=119, saving=False)
+    assert agent.step == 120 and agent.rule == 'sum'
+    assert len(agent.train_history) == 1 and any('ma_100 = ' in str(ln) for ln in logs)
+    assert agent.top_game is not None and agent.top_game.score == agent.top_score > 0
+    assert any('new best game at episode' in str(ln) for ln in logs) and any('Total time' in str(ln) for ln in logs)
+    results = api.QAgent.trial(estimator=api.score_eval, num=2, storage='local', console='local')     # host-driven path
+    assert len(results) == 2 and results[0].score >= results[1].score
+
+
 def test_agent_pickle_round_trip(api, tmp_path):
     agent = api.QAgent(name=str(tmp_path / 'agent_a'), storage='local', console='local', n=2, alpha=0.1)
     agent.step, agent.top_score = 12, 345
