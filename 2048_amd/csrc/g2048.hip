@@ -31,9 +31,6 @@ using namespace g2048;
 namespace {
 
 constexpr int WG = 256;
-// representative feature of each LDS-owned symmetry orbit (n >= 4): outer line, inner line, corner square, edge square,
-// centre square, cross (find_orbits checks it)
-constexpr int ORBIT_REPS[6] = {0, 1, 8, 9, 12, 17};
 constexpr uint8_t HAS_PREV = G2048_LANE_HAS_PREV;
 constexpr uint8_t DONE = G2048_LANE_DONE;
 
@@ -406,20 +403,11 @@ struct TdRecs {
     uint32_t* qcount;       // length of this step's queue
     uint32_t* qcount_next;  // next step's counter, zeroed by k_td_play
     uint32_t unit;          // 1: every record counts as dw = 1 (the counting pass of the per-slot mean rule)
-    // n >= 4: the orbit-table indices of every lane's `state`, computed once by k_td_play when the state was made
-    // (8 images x 5 four-cell orbits as u16, 8 images x the cross orbit as u32), so that the owner workgroups — each
-    // record is scanned by ~25 of them — only load them instead of re-deriving them from the board.
-    const uint4* qidx_cur;  // [5][B]: orbit o of lane i at qidx[o * B + i]; 8 x u16 = the 8 images
-    uint4* qidx_nxt;
-    const uint4* cidx_cur;  // [B][2]: 8 x u32 (n >= 5)
-    uint4* cidx_nxt;
-    uint32_t* qlane;        // [B] the lane of each terminal record (its indices are at *_nxt[lane])
 };
 
-__device__ __forceinline__ void push_terminal(const TdRecs& r, const Packed& state, float dw, uint32_t lane) {
+__device__ __forceinline__ void push_terminal(const TdRecs& r, const Packed& state, float dw) {
     uint32_t slot = atomicAdd(r.qcount, 1u);        // the compiler folds the wave's increments into one atomic
     st_packed(r.qstate, slot, state);
-    r.qlane[slot] = lane;
     r.qdw[slot] = dw;
 }
 
@@ -471,46 +459,6 @@ __device__ __forceinline__ void log_step(const GameLog& lg, uint32_t i, uint32_t
     m[1] = cnt;
 }
 
-// The orbit-table indices of a state for all 8 images (n >= 4): orbit o's representative feature ORBIT_REPS[o]
-// evaluated on every image.  Five u16 x 8 (one uint4 per orbit) and, for n >= 5, the cross orbit's u32 x 8.
-template <int N>
-__device__ __forceinline__ void store_orbit_indices(const TdRecs& r, uint32_t lane, uint32_t B, const Packed& state) {
-    if constexpr (N >= 4) {
-        constexpr int F = Shape<N>::F;
-        uint32_t q[5][8], x[8];
-#pragma unroll
-        for (uint32_t g = 0; g < 8; ++g) {
-            uint32_t s[F];
-            feature_slots<N>(d4_image(state, g), s);
-            q[0][g] = s[0] - feature_offset(N, 0);
-            q[1][g] = s[1] - feature_offset(N, 1);
-            q[2][g] = s[8] - feature_offset(N, 8);
-            q[3][g] = s[9] - feature_offset(N, 9);
-            q[4][g] = s[12] - feature_offset(N, 12);
-            if constexpr (N >= 5) x[g] = s[17] - feature_offset(N, 17);
-        }
-#pragma unroll
-        for (int o = 0; o < 5; ++o)
-            r.qidx_nxt[(size_t)o * B + lane] = make_uint4(q[o][0] | q[o][1] << 16, q[o][2] | q[o][3] << 16, q[o][4] | q[o][5] << 16, q[o][6] | q[o][7] << 16);
-        if constexpr (N >= 5) {
-            r.cidx_nxt[2 * (size_t)lane] = make_uint4(x[0], x[1], x[2], x[3]);
-            r.cidx_nxt[2 * (size_t)lane + 1] = make_uint4(x[4], x[5], x[6], x[7]);
-        }
-    }
-}
-
-template <int N>
-__device__ __forceinline__ void copy_orbit_indices(const TdRecs& r, uint32_t lane, uint32_t B) {
-    if constexpr (N >= 4) {
-#pragma unroll
-        for (int o = 0; o < 5; ++o) r.qidx_nxt[(size_t)o * B + lane] = r.qidx_cur[(size_t)o * B + lane];
-        if constexpr (N >= 5) {
-            r.cidx_nxt[2 * (size_t)lane] = r.cidx_cur[2 * (size_t)lane];
-            r.cidx_nxt[2 * (size_t)lane + 1] = r.cidx_cur[2 * (size_t)lane + 1];
-        }
-    }
-}
-
 // Step part 1 — the body of `while not game.game_over` in QAgent.episode (r_learning.py:228-246) for every live
 // lane, all reading the same table.  `prev` is double-buffered: prev_cur holds `state`, prev_nxt receives this
 // step's afterstate, so the main record needs no copy.
@@ -543,7 +491,6 @@ __global__ __launch_bounds__(WG) void k_td_play(uint4* boards, int32_t* scores, 
                 score += reward;
                 Packed after = pack_board(ch.after);
                 st_packed(prev_nxt, i, after);
-                store_orbit_indices<N>(recs, i, B, after);
                 old_label = c.value;
                 fl |= HAS_PREV;
                 moved = true;
@@ -561,13 +508,12 @@ __global__ __launch_bounds__(WG) void k_td_play(uint4* boards, int32_t* scores, 
                 }
                 overflow = max_tile(b) >= 16u;
                 over = game_over(b) || overflow;
-                if (over) push_terminal(recs, after, -c.value * alpha / F, i);
+                if (over) push_terminal(recs, after, -c.value * alpha / F);
             } else {
                 // a dead board was loaded: the reference's loop would not run; only the terminal update remains
                 over = true;
                 prev_nxt[i] = recs.state1[i];
-                copy_orbit_indices<N>(recs, i, B);
-                if (fl & HAS_PREV) push_terminal(recs, ld_packed(recs.state1, i), -old_label * alpha / F, i);
+                if (fl & HAS_PREV) push_terminal(recs, ld_packed(recs.state1, i), -old_label * alpha / F);
             }
             const int32_t final_score = score;
             if (over) {
@@ -676,7 +622,9 @@ constexpr uint32_t OWN_SLOTS = 32768;      // 128 KiB of the CU's 160 KiB LDS
 template <int FC> struct OwnUnroll { static constexpr int U = FC == 1 ? 4 : 1; };   // records in flight per thread (loads issued together)
 
 // variant v of table N covers features [f0(v), f0(v) + fc(v))
-// n >= 4: one variant per LDS-owned orbit (ORBIT_REPS)
+// n >= 4: one variant per LDS-owned orbit, encoding the orbit's representative feature (outer line 0, inner line 1,
+// corner square 8, edge square 9, centre square 12, cross 17; find_orbits checks that these are the representatives)
+constexpr int ORBIT_REPS[6] = {0, 1, 8, 9, 12, 17};
 template <int N> struct OwnVariants { static constexpr int COUNT = N == 4 ? 5 : 6; static constexpr int f0(int v) { return ORBIT_REPS[v]; } static constexpr int fc(int) { return 1; } };
 template <> struct OwnVariants<2> { static constexpr int COUNT = 1; static constexpr int f0(int) { return 0; } static constexpr int fc(int) { return 24; } };
 template <> struct OwnVariants<3> { static constexpr int COUNT = 7; static constexpr int f0(int v) { return 8 * v; } static constexpr int fc(int v) { return v < 6 ? 8 : 4; } };
@@ -713,97 +661,13 @@ __device__ __forceinline__ void own_accum(const Packed& p, float dw, bool valid,
     }
 }
 
-// one orbit-table index of one record: LDS add if this workgroup holds its chunk, else (fallback duty) straight into D
-template <bool FB>
-__device__ __forceinline__ void own_add(uint32_t idx, float dw, bool valid, float* acc, const Slice& sl, uint32_t rel_lo, uint32_t& nhit, float* D,
-                                        uint32_t* fb_hits) {
-    const uint32_t local = idx - rel_lo;
-    const bool hit = valid && local < sl.size;
-    if (hit) atomicAdd(&acc[local], dw);
-    nhit += hit ? 1u : 0u;
-    if (FB && valid && !hit) {
-        const uint32_t ch = idx / OWN_SLOTS;
-        if ((sl.fb_mask >> ch) & 1u) {
-            __hip_atomic_fetch_add(&D[sl.orb_dlo + idx], dw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            atomicAdd(&fb_hits[ch], 1u);            // LDS counter, flushed once per workgroup
-        }
-    }
-}
-
-template <bool FB>
-__device__ __forceinline__ void own_add8_u16(const uint4& v, float dw, bool valid, float* acc, const Slice& sl, uint32_t rel_lo, uint32_t& nhit,
-                                             float* D, uint32_t* fb_hits) {
-    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        own_add<FB>(w[j] & 0xFFFFu, dw, valid, acc, sl, rel_lo, nhit, D, fb_hits);
-        own_add<FB>(w[j] >> 16, dw, valid, acc, sl, rel_lo, nhit, D, fb_hits);
-    }
-}
-
-template <bool FB>
-__device__ __forceinline__ void own_add4_u32(const uint4& v, float dw, bool valid, float* acc, const Slice& sl, uint32_t rel_lo, uint32_t& nhit,
-                                             float* D, uint32_t* fb_hits) {
-    own_add<FB>(v.x, dw, valid, acc, sl, rel_lo, nhit, D, fb_hits);
-    own_add<FB>(v.y, dw, valid, acc, sl, rel_lo, nhit, D, fb_hits);
-    own_add<FB>(v.z, dw, valid, acc, sl, rel_lo, nhit, D, fb_hits);
-    own_add<FB>(v.w, dw, valid, acc, sl, rel_lo, nhit, D, fb_hits);
-}
-
 template <int N, int V, bool FB>
 __device__ __forceinline__ void own_run(float* acc, const Slice& s, const TdRecs& recs, uint32_t B, uint32_t* hits, float* D, uint32_t* fb_hits) {
     constexpr int F0 = OwnVariants<N>::f0(V), FC = OwnVariants<N>::fc(V), OWN_UNROLL = OwnUnroll<FC>::U;
     uint32_t nhit = 0;
-    const uint32_t begin = (uint32_t)((uint64_t)B * s.part / s.nparts), end = (uint32_t)((uint64_t)B * (s.part + 1) / s.nparts);
-    const uint32_t q = *recs.qcount;
-    const uint32_t qbegin = (uint32_t)((uint64_t)q * s.part / s.nparts), qend = (uint32_t)((uint64_t)q * (s.part + 1) / s.nparts);
-    if constexpr (N >= 4) {
-        // n >= 4: the record's orbit indices were computed by k_td_play; variant V = orbit V (0..4 four-cell, 5 cross)
-        const uint32_t rel_lo = s.tlo - s.orb_tlo;              // where this chunk starts inside its orbit table
-        constexpr bool CROSS = V == 5;
-        for (uint32_t base0 = begin; base0 < end; base0 += OWN_WG * OWN_UNROLL) {
-            uint4 a[OWN_UNROLL], b2[OWN_UNROLL];
-            float dw[OWN_UNROLL];
-#pragma unroll
-            for (int u = 0; u < OWN_UNROLL; ++u) {
-                const uint32_t r = base0 + threadIdx.x + (uint32_t)u * OWN_WG;
-                const bool ok = r < end;
-                const uint32_t rr = ok ? r : end - 1;
-                if (CROSS) {
-                    a[u] = recs.cidx_cur[2 * (size_t)rr];
-                    b2[u] = recs.cidx_cur[2 * (size_t)rr + 1];
-                } else {
-                    a[u] = recs.qidx_cur[(size_t)V * B + rr];
-                }
-                dw[u] = ok ? recs.dw1[rr] : 0.0f;
-                if (recs.unit) dw[u] = dw[u] != 0.0f ? 1.0f : 0.0f;
-            }
-#pragma unroll
-            for (int u = 0; u < OWN_UNROLL; ++u) {
-                const bool valid = dw[u] != 0.0f;
-                if (CROSS) {
-                    own_add4_u32<FB>(a[u], dw[u], valid, acc, s, rel_lo, nhit, D, fb_hits);
-                    own_add4_u32<FB>(b2[u], dw[u], valid, acc, s, rel_lo, nhit, D, fb_hits);
-                } else {
-                    own_add8_u16<FB>(a[u], dw[u], valid, acc, s, rel_lo, nhit, D, fb_hits);
-                }
-            }
-        }
-        for (uint32_t base0 = qbegin; base0 < qend; base0 += OWN_WG) {         // terminal queue: indices of the lane's new state
-            const uint32_t r = base0 + threadIdx.x;
-            const bool ok = r < qend;
-            const uint32_t rr = ok ? r : qend - 1;
-            const uint32_t lane = recs.qlane[rr];
-            const float dw = recs.unit ? 1.0f : recs.qdw[rr];
-            if (CROSS) {
-                own_add4_u32<FB>(recs.cidx_nxt[2 * (size_t)lane], dw, ok, acc, s, rel_lo, nhit, D, fb_hits);
-                own_add4_u32<FB>(recs.cidx_nxt[2 * (size_t)lane + 1], dw, ok, acc, s, rel_lo, nhit, D, fb_hits);
-            } else {
-                own_add8_u16<FB>(recs.qidx_nxt[(size_t)V * B + lane], dw, ok, acc, s, rel_lo, nhit, D, fb_hits);
-            }
-        }
-    } else {
-        // n = 2, 3: encode the record's features here (24 or 8 features per workgroup, no orbits)
+    {   // main records: this part's share of the lanes, OWN_UNROLL records per thread in flight; the loop bounds are
+        // wave-uniform
+        const uint32_t begin = (uint32_t)((uint64_t)B * s.part / s.nparts), end = (uint32_t)((uint64_t)B * (s.part + 1) / s.nparts);
         for (uint32_t base0 = begin; base0 < end; base0 += OWN_WG * OWN_UNROLL) {
             uint4 st[OWN_UNROLL];
             float dw[OWN_UNROLL];
@@ -819,10 +683,14 @@ __device__ __forceinline__ void own_run(float* acc, const Slice& s, const TdRecs
 #pragma unroll
             for (int u = 0; u < OWN_UNROLL; ++u) own_accum<N, F0, FC, FB>(unpack4(st[u]), dw[u], dw[u] != 0.0f, acc, s, nhit, D, fb_hits);
         }
-        for (uint32_t base0 = qbegin; base0 < qend; base0 += OWN_WG) {
+    }
+    {   // terminal queue
+        const uint32_t q = *recs.qcount;
+        const uint32_t begin = (uint32_t)((uint64_t)q * s.part / s.nparts), end = (uint32_t)((uint64_t)q * (s.part + 1) / s.nparts);
+        for (uint32_t base0 = begin; base0 < end; base0 += OWN_WG) {
             const uint32_t r = base0 + threadIdx.x;
-            const bool ok = r < qend;
-            const uint32_t rr = ok ? r : qend - 1;
+            const bool ok = r < end;
+            const uint32_t rr = ok ? r : end - 1;
             own_accum<N, F0, FC, FB>(ld_packed(recs.qstate, rr), recs.unit ? 1.0f : recs.qdw[rr], ok, acc, s, nhit, D, fb_hits);
         }
     }
@@ -1020,9 +888,6 @@ struct g2048_ctx {
     uint4* qstate = nullptr;            // terminal-record queue
     float* qdw = nullptr;
     uint32_t* qcount = nullptr;         // [2]: this step's / next step's queue length
-    uint4* qidx[2] = {nullptr, nullptr};   // orbit indices of `state` (n >= 4), double-buffered like prev
-    uint4* cidx[2] = {nullptr, nullptr};
-    uint32_t* qlane = nullptr;
     uint16_t* last_move = nullptr;      // what every lane did in the latest TD step (g2048_get_last_move)
     GameLog log = {0, 0, nullptr, nullptr, nullptr};
     uint32_t step_parity = 0;
@@ -1371,11 +1236,6 @@ int launch_td_step(g2048_ctx* c, float alpha, hipEvent_t ev = nullptr) {
     recs.qcount = c->qcount + c->step_parity;
     recs.qcount_next = c->qcount + (c->step_parity ^ 1u);
     recs.unit = 0;
-    recs.qidx_cur = c->qidx[c->cur];
-    recs.qidx_nxt = c->qidx[c->cur ^ 1];
-    recs.cidx_cur = c->cidx[c->cur];
-    recs.cidx_nxt = c->cidx[c->cur ^ 1];
-    recs.qlane = c->qlane;
     BY_N(c, (k_td_play<N><<<grid_for(B), WG, 0, c->stream>>>(c->boards, c->scores, c->rng, pn, c->label, c->flags, B, c->w, alpha, recs,
                                                              c->auto_reset, c->stats, c->last_move, c->log)));
     if (ev) (void)hipEventRecord(ev, c->stream);
@@ -1477,7 +1337,7 @@ int g2048_destroy(g2048_ctx* c) {
     if (!c) return G2048_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void* bufs[] = {c->qidx[0], c->qidx[1], c->cidx[0], c->cidx[1], c->qlane, c->log.moves, c->log.start, c->log.meta, c->boards, c->scores, c->rng, c->prev[0], c->prev[1], c->label, c->flags, c->dw1, c->qstate,
+    void* bufs[] = {c->log.moves, c->log.start, c->log.meta, c->boards, c->scores, c->rng, c->prev[0], c->prev[1], c->label, c->flags, c->dw1, c->qstate,
                     c->qdw,    c->qcount, c->last_move, c->w,      c->w0,  c->delta,   c->stats,   c->scratch, c->slices, c->hits, c->D, c->Dcnt};
     for (void* p : bufs)
         if (p && (p != (void*)c->w || c->owns_table)) (void)hipFree(p);
@@ -1525,12 +1385,6 @@ static int create_impl(int device, uint32_t batch, int n_tuple, uint64_t seed, u
         (rc = dalloc(c, &c->qcount, 2)) || (rc = dalloc(c, &c->last_move, B)) ||
         (rc = dalloc(c, &c->stats, 1)))
         return bail(rc);
-    if (n_tuple >= 4) {
-        if ((rc = dalloc(c, &c->qidx[0], 5 * B)) || (rc = dalloc(c, &c->qidx[1], 5 * B)) || (rc = dalloc(c, &c->qlane, B))) return bail(rc);
-        if (n_tuple >= 5 && ((rc = dalloc(c, &c->cidx[0], 2 * B)) || (rc = dalloc(c, &c->cidx[1], 2 * B)))) return bail(rc);
-    } else if (n_tuple) {
-        if ((rc = dalloc(c, &c->qlane, B))) return bail(rc);
-    }
     if (parent) {
         c->w = parent->w;
         c->owns_table = false;
