@@ -76,7 +76,8 @@ def measured_copy_gbps(device):
         stop.record()
         stop.synchronize()
         return 2 * a.numel() * 10 / (start.elapsed_time(stop) * 1e-3) / 1e9
-    except Exception:
+    except Exception as e:              # never let the side measurement break the benchmark line
+        print(f'[bench] copy-bandwidth measurement skipped: {e!r}', file=sys.stderr)
         return None
 
 
