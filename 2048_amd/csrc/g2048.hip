@@ -72,6 +72,7 @@ static_assert(sizeof(Stats) == sizeof(g2048_stats), "stats layout");
 struct WgStats {
     unsigned long long score_sum;
     unsigned int episodes, moves, best, overflow16, max_tile[20];
+    unsigned int dw_max_bits;       // largest |dw| of the workgroup's records, as float bits (orders like an unsigned int)
 };
 
 __device__ __forceinline__ void wg_stats_init(WgStats* ws) {
@@ -79,6 +80,7 @@ __device__ __forceinline__ void wg_stats_init(WgStats* ws) {
     if (threadIdx.x == 0) {
         ws->score_sum = 0;
         ws->episodes = ws->moves = ws->best = ws->overflow16 = 0;
+        ws->dw_max_bits = 0;
     }
     __syncthreads();
 }
@@ -403,6 +405,8 @@ struct TdRecs {
     uint32_t* qcount;       // length of this step's queue
     uint32_t* qcount_next;  // next step's counter, zeroed by k_td_play
     uint32_t unit;          // 1: every record counts as dw = 1 (the counting pass of the per-slot mean rule)
+    uint32_t* dwmax;        // float bits of the largest |dw| among this step's records (scale of the fixed-point sums)
+    uint32_t* dwmax_next;   // next step's, zeroed by k_td_play
 };
 
 __device__ __forceinline__ void push_terminal(const TdRecs& r, const Packed& state, float dw) {
@@ -470,8 +474,12 @@ __global__ __launch_bounds__(WG) void k_td_play(uint4* boards, int32_t* scores, 
     __shared__ WgStats ws;
     wg_stats_init(&ws);
     uint32_t i = blockIdx.x * WG + threadIdx.x;
-    if (i == 0) *recs.qcount_next = 0;
+    if (i == 0) {
+        *recs.qcount_next = 0;
+        *recs.dwmax_next = 0;
+    }
     bool moved = false;
+    float dw_big = 0.0f;            // largest |dw| this lane emits
     if (i < B) {
         uint8_t fl = flags[i];
         float dw1 = 0.0f;
@@ -508,12 +516,20 @@ __global__ __launch_bounds__(WG) void k_td_play(uint4* boards, int32_t* scores, 
                 }
                 overflow = max_tile(b) >= 16u;
                 over = game_over(b) || overflow;
-                if (over) push_terminal(recs, after, -c.value * alpha / F);
+                if (over) {
+                    const float dw2 = -c.value * alpha / F;
+                    push_terminal(recs, after, dw2);
+                    dw_big = fabsf(dw2);
+                }
             } else {
                 // a dead board was loaded: the reference's loop would not run; only the terminal update remains
                 over = true;
                 prev_nxt[i] = recs.state1[i];
-                if (fl & HAS_PREV) push_terminal(recs, ld_packed(recs.state1, i), -old_label * alpha / F);
+                if (fl & HAS_PREV) {
+                    const float dw2 = -old_label * alpha / F;
+                    push_terminal(recs, ld_packed(recs.state1, i), dw2);
+                    dw_big = fabsf(dw2);
+                }
             }
             const int32_t final_score = score;
             if (over) {
@@ -537,9 +553,12 @@ __global__ __launch_bounds__(WG) void k_td_play(uint4* boards, int32_t* scores, 
         }
         recs.dw1[i] = dw1;
         last_move[i] = (uint16_t)lm;
+        dw_big = fmaxf(dw_big, fabsf(dw1));
     }
+    if (dw_big > 0.0f && isfinite(dw_big)) atomicMax(&ws.dw_max_bits, __float_as_uint(dw_big));
     count_moves(&ws, moved ? 1u : 0u);
     wg_stats_flush(&ws, stats);
+    if (threadIdx.x == 0 && ws.dw_max_bits) atomicMax(recs.dwmax, ws.dw_max_bits);
 }
 
 // Step part 2, global-atomics form — QAgent.update for every record: thread t adds image (t & 7) of record (t >> 3);
@@ -575,6 +594,7 @@ struct Slice {
     // added straight into D with global atomics by the orbit's busiest chunk: bit k of fb_mask = chunk k of the orbit
     // is this workgroup's duty.  orb_tlo / orb_dlo / chunk0: first table slot, first D index, first hit counter of the orbit.
     uint32_t fb_mask, orb_tlo, orb_dlo, chunk0;
+    uint32_t csize;         // slots per chunk of this orbit table (OWN_SLOTS, or OWN_SLOTS / 2 for the fixed-point four-cell orbits)
 };
 
 // Symmetry orbits (n >= 4).  QAgent.update adds dw at f_i(g.x) for all 8 images g (r_learning.py:207-214).  Features
@@ -629,6 +649,10 @@ template <int N> struct OwnVariants { static constexpr int COUNT = N == 4 ? 5 : 
 template <> struct OwnVariants<2> { static constexpr int COUNT = 1; static constexpr int f0(int) { return 0; } static constexpr int fc(int) { return 24; } };
 template <> struct OwnVariants<3> { static constexpr int COUNT = 7; static constexpr int f0(int v) { return 8 * v; } static constexpr int fc(int v) { return v < 6 ? 8 : 4; } };
 
+// which variants sum in 64-bit fixed point: the five four-cell orbits of n >= 4
+constexpr bool own_fixed(int n, int variant) { return n >= 4 && variant < 5; }
+constexpr uint32_t FIXED_SLOTS = OWN_SLOTS / 2;
+
 __device__ __forceinline__ Packed unpack4(const uint4& v) {
     Packed q;
     q.R[0] = v.x & 0xFFFFu; q.R[1] = v.x >> 16; q.R[2] = v.y & 0xFFFFu; q.R[3] = v.y >> 16;
@@ -636,10 +660,17 @@ __device__ __forceinline__ Packed unpack4(const uint4& v) {
     return q;
 }
 
-template <int N, int F0, int FC, bool FB>
+// FIXED: the four-cell orbits (n >= 4) take 40 of a record's 48 adds, and `ds_add_f32` manages 0.33 lane-adds per
+// cycle per CU against 4.1 for `ds_add_u64` (profiles/r01_lds_atomic_microbench.txt).  Their workgroups therefore sum
+// in 64-bit fixed point: dw * 2^S with S chosen from the step's largest |dw| so that 2^24 adds cannot overflow and a
+// dw 2^-14 times smaller than the largest is still exact; the flush converts back.  Half as many slots fit in LDS
+// (chunks of 16 384), the sums no longer depend on the order of the adds.
+template <int N, int F0, int FC, bool FB, bool FIXED>
 __device__ __forceinline__ void own_accum(const Packed& p, float dw, bool valid, float* acc, const Slice& sl, uint32_t& nhit, float* D,
-                                          uint32_t* fb_hits) {
+                                          uint32_t* fb_hits, float scale) {
     constexpr int F = Shape<N>::F;
+    long long fixed = 0;
+    if (FIXED) fixed = __float2ll_rn(dw * scale);
 #pragma unroll
     for (uint32_t g = 0; g < 8; ++g) {
         uint32_t s[F];
@@ -648,10 +679,15 @@ __device__ __forceinline__ void own_accum(const Packed& p, float dw, bool valid,
         for (int f = F0; f < F0 + FC; ++f) {
             const uint32_t local = s[f] - sl.tlo;
             const bool hit = valid && local < sl.size;
-            if (hit) atomicAdd(&acc[local], dw);
+            if (hit) {
+                if (FIXED)
+                    atomicAdd(reinterpret_cast<unsigned long long*>(acc) + local, (unsigned long long)fixed);
+                else
+                    atomicAdd(&acc[local], dw);
+            }
             nhit += hit ? 1u : 0u;
             if (FB && valid && !hit) {
-                const uint32_t rel = s[f] - sl.orb_tlo, ch = rel / OWN_SLOTS;
+                const uint32_t rel = s[f] - sl.orb_tlo, ch = rel / sl.csize;
                 if ((sl.fb_mask >> ch) & 1u) {
                     __hip_atomic_fetch_add(&D[sl.orb_dlo + rel], dw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     atomicAdd(&fb_hits[ch], 1u);            // LDS counter, flushed once per workgroup
@@ -662,8 +698,10 @@ __device__ __forceinline__ void own_accum(const Packed& p, float dw, bool valid,
 }
 
 template <int N, int V, bool FB>
-__device__ __forceinline__ void own_run(float* acc, const Slice& s, const TdRecs& recs, uint32_t B, uint32_t* hits, float* D, uint32_t* fb_hits) {
+__device__ __forceinline__ void own_run(float* acc, const Slice& s, const TdRecs& recs, uint32_t B, uint32_t* hits, float* D, uint32_t* fb_hits,
+                                        float scale) {
     constexpr int F0 = OwnVariants<N>::f0(V), FC = OwnVariants<N>::fc(V), OWN_UNROLL = OwnUnroll<FC>::U;
+    constexpr bool FIXED = own_fixed(N, V);
     uint32_t nhit = 0;
     {   // main records: this part's share of the lanes, OWN_UNROLL records per thread in flight; the loop bounds are
         // wave-uniform
@@ -681,7 +719,7 @@ __device__ __forceinline__ void own_run(float* acc, const Slice& s, const TdRecs
                 if (recs.unit) dw[u] = dw[u] != 0.0f ? 1.0f : 0.0f;
             }
 #pragma unroll
-            for (int u = 0; u < OWN_UNROLL; ++u) own_accum<N, F0, FC, FB>(unpack4(st[u]), dw[u], dw[u] != 0.0f, acc, s, nhit, D, fb_hits);
+            for (int u = 0; u < OWN_UNROLL; ++u) own_accum<N, F0, FC, FB, FIXED>(unpack4(st[u]), dw[u], dw[u] != 0.0f, acc, s, nhit, D, fb_hits, scale);
         }
     }
     {   // terminal queue
@@ -691,7 +729,7 @@ __device__ __forceinline__ void own_run(float* acc, const Slice& s, const TdRecs
             const uint32_t r = base0 + threadIdx.x;
             const bool ok = r < end;
             const uint32_t rr = ok ? r : end - 1;
-            own_accum<N, F0, FC, FB>(ld_packed(recs.qstate, rr), recs.unit ? 1.0f : recs.qdw[rr], ok, acc, s, nhit, D, fb_hits);
+            own_accum<N, F0, FC, FB, FIXED>(ld_packed(recs.qstate, rr), recs.unit ? 1.0f : recs.qdw[rr], ok, acc, s, nhit, D, fb_hits, scale);
         }
     }
     // load statistics for the planner: one counter bump per wave
@@ -702,17 +740,17 @@ __device__ __forceinline__ void own_run(float* acc, const Slice& s, const TdRecs
 
 template <int N, int V>
 __device__ __forceinline__ void own_dispatch(float* acc, const Slice& s, const TdRecs& recs, uint32_t B, uint32_t* hits, float* D,
-                                             uint32_t* fb_hits) {
+                                             uint32_t* fb_hits, float scale) {
     if constexpr (V < OwnVariants<N>::COUNT) {
         if (s.variant == (uint32_t)V) {
             // the fallback duty (global atomics for chunks nobody holds in LDS) is carried by few workgroups: two
             // instantiations keep its tests out of everybody else's inner loop
             if (N >= 4 && s.fb_mask)
-                own_run<N, V, true>(acc, s, recs, B, hits, D, fb_hits);
+                own_run<N, V, true>(acc, s, recs, B, hits, D, fb_hits, scale);
             else
-                own_run<N, V, false>(acc, s, recs, B, hits, D, fb_hits);
+                own_run<N, V, false>(acc, s, recs, B, hits, D, fb_hits, scale);
         } else
-            own_dispatch<N, V + 1>(acc, s, recs, B, hits, D, fb_hits);
+            own_dispatch<N, V + 1>(acc, s, recs, B, hits, D, fb_hits, scale);
     }
 }
 
@@ -722,21 +760,35 @@ __global__ __launch_bounds__(OWN_WG) void k_td_update_owner(float* dst, TdRecs r
     __shared__ float acc[OWN_SLOTS];
     __shared__ uint32_t fb_hits[32];
     const Slice s = slices[blockIdx.x];
-    for (uint32_t j = threadIdx.x; j < s.size; j += OWN_WG) acc[j] = 0.0f;
+    const bool fixed = own_fixed(N, (int)s.variant);
+    // fixed-point scale 2^S from the step's largest |dw| (< 2^e): 2^24 adds of at most 2^(e+S) stay below 2^62
+    float scale = 1.0f, inv_scale = 1.0f;
+    if (fixed) {
+        const float big = recs.unit ? 1.0f : __uint_as_float(*recs.dwmax);
+        int e = big > 0.0f ? ilogbf(big) + 1 : 0;
+        int S = 38 - e;
+        S = S > 100 ? 100 : (S < -60 ? -60 : S);
+        scale = ldexpf(1.0f, S);
+        inv_scale = ldexpf(1.0f, -S);
+    }
+    const uint32_t words = fixed ? 2 * s.size : s.size;        // a fixed-point slot is two LDS words
+    for (uint32_t j = threadIdx.x; j < words; j += OWN_WG) acc[j] = 0.0f;
     if (threadIdx.x < 32) fb_hits[threadIdx.x] = 0;
     __syncthreads();
-    own_dispatch<N, 0>(acc, s, recs, B, hits, dst, fb_hits);
+    own_dispatch<N, 0>(acc, s, recs, B, hits, dst, fb_hits, scale);
     __syncthreads();
     if (threadIdx.x < 32 && fb_hits[threadIdx.x]) atomicAdd(&hits[s.chunk0 + threadIdx.x], fb_hits[threadIdx.x]);
-    if (s.nparts == 1) {
-        for (uint32_t j = threadIdx.x; j < s.size; j += OWN_WG) {
-            float v = acc[j];
-            if (v != 0.0f) dst[s.dlo + j] += v;         // this workgroup is the only writer of the slice
-        }
-    } else {
-        for (uint32_t j = threadIdx.x; j < s.size; j += OWN_WG) {
-            float v = acc[j];
-            if (v != 0.0f) __hip_atomic_fetch_add(&dst[s.dlo + j], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (uint32_t j = threadIdx.x; j < s.size; j += OWN_WG) {
+        float v;
+        if (fixed)
+            v = (float)((double)(long long)reinterpret_cast<const unsigned long long*>(acc)[j] * (double)inv_scale);
+        else
+            v = acc[j];
+        if (v != 0.0f) {
+            if (s.nparts == 1)
+                dst[s.dlo + j] += v;                               // this workgroup is the only writer of the slice
+            else
+                __hip_atomic_fetch_add(&dst[s.dlo + j], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -887,7 +939,7 @@ struct g2048_ctx {
     float* dw1 = nullptr;               // main record of every lane (0 = none)
     uint4* qstate = nullptr;            // terminal-record queue
     float* qdw = nullptr;
-    uint32_t* qcount = nullptr;         // [2]: this step's / next step's queue length
+    uint32_t* qcount = nullptr;         // [4]: this step's / next step's queue length, then this / next step's largest |dw| bits
     uint16_t* last_move = nullptr;      // what every lane did in the latest TD step (g2048_get_last_move)
     GameLog log = {0, 0, nullptr, nullptr, nullptr};
     uint32_t step_parity = 0;
@@ -1115,8 +1167,9 @@ std::vector<ChunkInfo> table_chunks(const g2048_ctx* c) {
                 if (feature_offset(c->n, j) == oi.off[0]) rep = (uint32_t)j;
             const uint32_t first = (uint32_t)v.size();
             if (o >= 6 || (int)rep != ORBIT_REPS[o]) return {};      // (checked by the caller: empty plan = unexpected orbit structure)
-            for (uint32_t lo = 0; lo < oi.size; lo += OWN_SLOTS)
-                v.push_back({o, oi.off[0] + lo, OWN_SLOTS, oi.base + lo, oi.digits == 4 ? 1.0 : 2.0, oi.off[0], oi.base, first, oi.size / OWN_SLOTS});
+            const uint32_t csz = own_fixed(c->n, (int)o) ? FIXED_SLOTS : OWN_SLOTS;
+            for (uint32_t lo = 0; lo < oi.size; lo += csz)
+                v.push_back({o, oi.off[0] + lo, csz, oi.base + lo, oi.digits == 4 ? 1.0 : 2.0, oi.off[0], oi.base, first, oi.size / csz});
         }
     }
     return v;
@@ -1151,13 +1204,14 @@ int build_slices(g2048_ctx* c) {
         for (size_t k = 0; k < nc; ++k) {       // fresh games only touch small tiles: the low chunk of every table
             double share = 1.0;
             if (c->n >= 4) {
-                const uint32_t rel = (chunks[k].dlo % (chunks[k].scan == 1.0 ? 65536u : 1048576u)) / OWN_SLOTS;
-                share = chunks[k].scan == 1.0 ? (rel == 0 ? 0.99 : 0.01) : ((rel & 1) == 0 && rel < 16 ? 0.12 : 0.001);
+                const uint32_t rel = (chunks[k].dlo % (chunks[k].scan == 1.0 ? 65536u : 1048576u)) / chunks[k].size;
+                share = chunks[k].scan == 1.0 ? (rel == 0 ? 0.7 : rel == 1 ? 0.28 : 0.01) : ((rel & 1) == 0 && rel < 16 ? 0.12 : 0.001);
             }
             c->load[k] = 8.0 * c->B * share * (c->n == 2 ? 24 : c->n == 3 ? (chunks[k].size / 4096.0) : 1);
         }
     }
-    double add_cost = 1.5, thr = 0.01;
+    double add_cost = 1.5, thr = 0.01, fixed_ratio = 0.25;
+    if (const char* e = getenv("G2048_PLAN_FIXEDRATIO")) fixed_ratio = atof(e);
     if (const char* e = getenv("G2048_PLAN_ADDCOST")) add_cost = atof(e);      // (experiments)
     if (const char* e = getenv("G2048_PLAN_THR")) thr = atof(e);
     const double B = c->B;
@@ -1184,7 +1238,9 @@ int build_slices(g2048_ctx* c) {
     size_t n_lds = 0;
     for (size_t k = 0; k < nc; ++k)
         if (in_lds[k]) {
-            cost[k] = chunks[k].scan * B + add_cost * c->load[k];
+            // an add costs ~12x less where the sums are 64-bit fixed point (ds_add_u64) than where they are fp32 (ds_add_f32)
+            const double per_add = (c->n >= 4 && own_fixed(c->n, (int)chunks[k].variant)) ? add_cost * fixed_ratio : add_cost;
+            cost[k] = chunks[k].scan * B + per_add * c->load[k];
             total += cost[k];
             ++n_lds;
         }
@@ -1196,7 +1252,7 @@ int build_slices(g2048_ctx* c) {
         parts[k] = 1 + (uint32_t)((budget - n_lds) * cost[k] / total);
         for (uint32_t p = 0; p < parts[k]; ++p)
             v.push_back(Slice{chunks[k].variant, chunks[k].tlo, chunks[k].size, chunks[k].dlo, p, parts[k], (uint32_t)k, duty[k],
-                              chunks[k].orb_tlo, chunks[k].orb_dlo, chunks[k].chunk0});
+                              chunks[k].orb_tlo, chunks[k].orb_dlo, chunks[k].chunk0, chunks[k].size});
     }
     if (v.size() > MAX_SLICES) return fail(c, G2048_ERR_STATE, "LDS-owner plan too large");
     // longest-running workgroups first
@@ -1235,6 +1291,8 @@ int launch_td_step(g2048_ctx* c, float alpha, hipEvent_t ev = nullptr) {
     recs.qdw = c->qdw;
     recs.qcount = c->qcount + c->step_parity;
     recs.qcount_next = c->qcount + (c->step_parity ^ 1u);
+    recs.dwmax = c->qcount + 2 + c->step_parity;
+    recs.dwmax_next = c->qcount + 2 + (c->step_parity ^ 1u);
     recs.unit = 0;
     BY_N(c, (k_td_play<N><<<grid_for(B), WG, 0, c->stream>>>(c->boards, c->scores, c->rng, pn, c->label, c->flags, B, c->w, alpha, recs,
                                                              c->auto_reset, c->stats, c->last_move, c->log)));
@@ -1382,7 +1440,7 @@ static int create_impl(int device, uint32_t batch, int n_tuple, uint64_t seed, u
     if ((rc = dalloc(c, &c->boards, B)) || (rc = dalloc(c, &c->scores, B)) || (rc = dalloc(c, &c->rng, B)) ||
         (rc = dalloc(c, &c->prev[0], B)) || (rc = dalloc(c, &c->prev[1], B)) || (rc = dalloc(c, &c->label, B)) ||
         (rc = dalloc(c, &c->flags, B)) || (rc = dalloc(c, &c->dw1, B)) || (rc = dalloc(c, &c->qstate, B)) || (rc = dalloc(c, &c->qdw, B)) ||
-        (rc = dalloc(c, &c->qcount, 2)) || (rc = dalloc(c, &c->last_move, B)) ||
+        (rc = dalloc(c, &c->qcount, 4)) || (rc = dalloc(c, &c->last_move, B)) ||
         (rc = dalloc(c, &c->stats, 1)))
         return bail(rc);
     if (parent) {
@@ -1395,7 +1453,7 @@ static int create_impl(int device, uint32_t batch, int n_tuple, uint64_t seed, u
     if (hipMemsetAsync(c->stats, 0, sizeof(Stats), c->stream) != hipSuccess ||
         hipMemsetAsync(c->prev[0], 0, B * sizeof(uint4), c->stream) != hipSuccess ||
         hipMemsetAsync(c->prev[1], 0, B * sizeof(uint4), c->stream) != hipSuccess ||
-        hipMemsetAsync(c->qcount, 0, 8, c->stream) != hipSuccess || hipMemsetAsync(c->last_move, 0, B * 2, c->stream) != hipSuccess || hipMemsetAsync(c->dw1, 0, B * 4, c->stream) != hipSuccess ||
+        hipMemsetAsync(c->qcount, 0, 16, c->stream) != hipSuccess || hipMemsetAsync(c->last_move, 0, B * 2, c->stream) != hipSuccess || hipMemsetAsync(c->dw1, 0, B * 4, c->stream) != hipSuccess ||
         (slots && !parent && hipMemsetAsync(c->w, 0, slots * sizeof(float), c->stream) != hipSuccess))
         return bail(G2048_ERR_HIP);
     k_seed<<<grid_for(B), WG, 0, c->stream>>>(c->rng, batch, seed, lane0);

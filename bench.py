@@ -154,6 +154,8 @@ def main():
             torch.cuda.set_device(local_rank)
             dist.init_process_group(args.backend)
 
+    # torch first: it must initialise its HIP runtime before lib2048_hip.so brings up its own
+    copy_gbps = measured_copy_gbps(local_rank) if args.workload == 'td' else None
     pkg = importlib.import_module('2048_amd')
     par = importlib.import_module('2048_amd.parallel')
     if args.workload != 'td':
@@ -233,7 +235,7 @@ def main():
                          'algorithmic_bytes_per_launch': dom_bytes, 'ms_per_launch': dom_ms,
                          'ms_k_td_play': ms_play, 'ms_k_td_update': ms_update,
                          'whole_step_algorithmic_GBps': (by_play + by_update) * B / (dt / K) / 1e9,
-                         'measured_copy_GBps': measured_copy_gbps(local_rank)},
+                         'measured_copy_GBps': copy_gbps},
             'hip_event_ms_per_step': ev_ms / K,
             'episodes_finished': st['episodes'],
             'mean_score': st['score_sum'] / max(1, st['episodes']),
