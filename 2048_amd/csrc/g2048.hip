@@ -329,13 +329,55 @@ struct Choice {
     float v[4];
 };
 
-// greedy afterstate choice (r_learning.py:229-237): strict '>' from -inf keeps the first maximum
+// greedy afterstate choice (r_learning.py:229-237): strict '>' from -inf keeps the first maximum.
+// The table reads of ALL candidate directions are issued before any of them is summed: the kernel is bound by the
+// latency and rate of these 4-byte gathers (up to 4 x F per board, 64 separate lines per wave instruction), and one
+// round of 4 F loads in flight per lane hides far more of it than four rounds of F.  Directions that do not change the
+// board read slot 0 and are ignored (a few wasted loads of a hot line instead of a branch around every group).
 template <int N>
 __device__ __forceinline__ Choice choose(const float* __restrict__ w, const Moves4& mv) {
+    constexpr int F = Shape<N>::F;
     Choice c;
     c.action = -1;
     c.value = -INFINITY;
     int first_valid = -1;
+    if constexpr (F <= 24) {
+        uint32_t s0[F], s1[F], s2[F], s3[F];
+        feature_slots<N>(pack_board(mv.m0.after), s0);
+        feature_slots<N>(pack_board(mv.m1.after), s1);
+        feature_slots<N>(pack_board(mv.m2.after), s2);
+        feature_slots<N>(pack_board(mv.m3.after), s3);
+        float x0[F], x1[F], x2[F], x3[F];
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            x0[f] = w[mv.m0.changed ? s0[f] : 0u];
+            x1[f] = w[mv.m1.changed ? s1[f] : 0u];
+            x2[f] = w[mv.m2.changed ? s2[f] : 0u];
+            x3[f] = w[mv.m3.changed ? s3[f] : 0u];
+        }
+        float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f, v3 = 0.0f;      // each a left-to-right sum, as QAgent.evaluate
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            v0 += x0[f];
+            v1 += x1[f];
+            v2 += x2[f];
+            v3 += x3[f];
+        }
+        c.v[0] = mv.m0.changed ? v0 : -INFINITY;
+        c.v[1] = mv.m1.changed ? v1 : -INFINITY;
+        c.v[2] = mv.m2.changed ? v2 : -INFINITY;
+        c.v[3] = mv.m3.changed ? v3 : -INFINITY;
+        const bool ch[4] = {mv.m0.changed, mv.m1.changed, mv.m2.changed, mv.m3.changed};
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+            if (ch[d]) {
+                if (first_valid < 0) first_valid = d;
+                if (c.v[d] > c.value) {
+                    c.value = c.v[d];
+                    c.action = d;
+                }
+            }
+    } else {
 #define G2048_TRY_DIR(D, M)                                  \
     c.v[D] = -INFINITY;                                      \
     if ((M).changed) {                                       \
@@ -347,11 +389,12 @@ __device__ __forceinline__ Choice choose(const float* __restrict__ w, const Move
             c.action = D;                                    \
         }                                                    \
     }
-    G2048_TRY_DIR(0, mv.m0)
-    G2048_TRY_DIR(1, mv.m1)
-    G2048_TRY_DIR(2, mv.m2)
-    G2048_TRY_DIR(3, mv.m3)
+        G2048_TRY_DIR(0, mv.m0)
+        G2048_TRY_DIR(1, mv.m1)
+        G2048_TRY_DIR(2, mv.m2)
+        G2048_TRY_DIR(3, mv.m3)
 #undef G2048_TRY_DIR
+    }
     if (c.action < 0 && first_valid >= 0) {     // every value was -inf or NaN (a poisoned table): still make a legal move
         c.action = first_valid;
         c.value = c.v[first_valid];
