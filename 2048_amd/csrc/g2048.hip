@@ -377,25 +377,39 @@ __device__ __forceinline__ Choice choose(const float* __restrict__ w, const Move
                     c.action = d;
                 }
             }
+    } else if constexpr (F <= 40) {
+        // two directions per round (2 F loads in flight per lane)
+#define G2048_TRY_PAIR(DA, MA, DB, MB)                                               \
+    {                                                                                \
+        uint32_t sa[F], sb[F];                                                       \
+        feature_slots<N>(pack_board((MA).after), sa);                                \
+        feature_slots<N>(pack_board((MB).after), sb);                                \
+        float xa[F], xb[F];                                                          \
+        _Pragma("unroll") for (int f = 0; f < F; ++f) {                              \
+            xa[f] = w[(MA).changed ? sa[f] : 0u];                                    \
+            xb[f] = w[(MB).changed ? sb[f] : 0u];                                    \
+        }                                                                            \
+        float va = 0.0f, vb = 0.0f;                                                  \
+        _Pragma("unroll") for (int f = 0; f < F; ++f) {                              \
+            va += xa[f];                                                             \
+            vb += xb[f];                                                             \
+        }                                                                            \
+        c.v[DA] = (MA).changed ? va : -INFINITY;                                     \
+        c.v[DB] = (MB).changed ? vb : -INFINITY;                                     \
+        if ((MA).changed) {                                                          \
+            if (first_valid < 0) first_valid = DA;                                   \
+            if (va > c.value) { c.value = va; c.action = DA; }                       \
+        }                                                                            \
+        if ((MB).changed) {                                                          \
+            if (first_valid < 0) first_valid = DB;                                   \
+            if (vb > c.value) { c.value = vb; c.action = DB; }                       \
+        }                                                                            \
+    }
+        G2048_TRY_PAIR(0, mv.m0, 1, mv.m1)
+        G2048_TRY_PAIR(2, mv.m2, 3, mv.m3)
+#undef G2048_TRY_PAIR
     } else {
-#define G2048_TRY_DIR(D, M)                                  \
-    c.v[D] = -INFINITY;                                      \
-    if ((M).changed) {                                       \
-        if (first_valid < 0) first_valid = D;                \
-        float v = value_of<N>(w, (M).after);                 \
-        c.v[D] = v;                                          \
-        if (v > c.value) {                                   \
-            c.value = v;                                     \
-            c.action = D;                                    \
-        }                                                    \
-    }
-        G2048_TRY_DIR(0, mv.m0)
-        G2048_TRY_DIR(1, mv.m1)
-        G2048_TRY_DIR(2, mv.m2)
-        G2048_TRY_DIR(3, mv.m3)
-#undef G2048_TRY_DIR
-    }
-    if (c.action < 0 && first_valid >= 0) {     // every value was -inf or NaN (a poisoned table): still make a legal move
+#define G2048_TRY_DIR(D, M)    if (c.action < 0 && first_valid >= 0) {     // every value was -inf or NaN (a poisoned table): still make a legal move
         c.action = first_valid;
         c.value = c.v[first_valid];
     }
