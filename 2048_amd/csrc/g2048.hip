@@ -409,7 +409,24 @@ __device__ __forceinline__ Choice choose(const float* __restrict__ w, const Move
         G2048_TRY_PAIR(2, mv.m2, 3, mv.m3)
 #undef G2048_TRY_PAIR
     } else {
-#define G2048_TRY_DIR(D, M)    if (c.action < 0 && first_valid >= 0) {     // every value was -inf or NaN (a poisoned table): still make a legal move
+#define G2048_TRY_DIR(D, M)                                  \
+    c.v[D] = -INFINITY;                                      \
+    if ((M).changed) {                                       \
+        if (first_valid < 0) first_valid = D;                \
+        float v = value_of<N>(w, (M).after);                 \
+        c.v[D] = v;                                          \
+        if (v > c.value) {                                   \
+            c.value = v;                                     \
+            c.action = D;                                    \
+        }                                                    \
+    }
+        G2048_TRY_DIR(0, mv.m0)
+        G2048_TRY_DIR(1, mv.m1)
+        G2048_TRY_DIR(2, mv.m2)
+        G2048_TRY_DIR(3, mv.m3)
+#undef G2048_TRY_DIR
+    }
+    if (c.action < 0 && first_valid >= 0) {     // every value was -inf or NaN (a poisoned table): still make a legal move
         c.action = first_valid;
         c.value = c.v[first_valid];
     }
