@@ -667,7 +667,8 @@ struct Slice {
     // Chunks of the same orbit table that nobody holds in LDS (they see too few adds to be worth a record scan) are
     // added straight into D with global atomics by the orbit's busiest chunk: bit k of fb_mask = chunk k of the orbit
     // is this workgroup's duty.  orb_tlo / orb_dlo / chunk0: first table slot, first D index, first hit counter of the orbit.
-    uint32_t fb_mask, orb_tlo, orb_dlo, chunk0;
+    uint32_t orb_tlo, orb_dlo, chunk0;
+    uint64_t fb_mask;
     uint32_t csize;         // slots per chunk of this orbit table (OWN_SLOTS, or OWN_SLOTS / 2 for the fixed-point four-cell orbits)
 };
 
@@ -684,6 +685,11 @@ struct OrbitInfo {
     uint32_t off[MAX_MEMBERS];          // first table slot of each member feature
     uint32_t perm[MAX_MEMBERS];         // 3 bits per output digit p: the input digit it takes (out digit p = in digit src[p])
     uint32_t digits, radix;             // 4 or 5 digits in base 16 (nibbles), or 6 digits in base 14 (the f_6 features)
+    // Stabiliser of the representative: the images g with f_rep(g.x) = sigma_g(f_rep(x)) (the feature's cells map onto
+    // themselves; e.g. the up-down mirror reverses the nibbles of a column).  The owner kernel then visits only one image
+    // per coset (COSET_MASK) and accumulates E; the orbit table is D[k] = sum over the stabiliser of E[sigma(k)].
+    uint32_t nstab;
+    uint32_t sperm[8];                  // digit permutations of the stabiliser (sperm[0] = identity), encoded like perm
 };
 struct OrbitTable {
     uint32_t count, total;
@@ -719,12 +725,20 @@ template <int FC> struct OwnUnroll { static constexpr int U = FC == 1 ? 4 : 1; }
 // n >= 4: one variant per LDS-owned orbit, encoding the orbit's representative feature (outer line 0, inner line 1,
 // corner square 8, edge square 9, centre square 12, cross 17; find_orbits checks that these are the representatives)
 constexpr int ORBIT_REPS[6] = {0, 1, 8, 9, 12, 17};
+// images (bit g = d4_image g) that the owner kernel visits for each representative: one per coset of its stabiliser
+// (columns 0 / 1: up-down mirror; corner square and cross: transpose; edge square: left-right mirror; the centre square
+// is fixed by the whole group).  4 + 4 + 4 + 4 + 1 + 4 = 21 LDS adds per record instead of 48.  find_orbits verifies
+// these masks against the brute-force enumeration of all 8 images.
+constexpr uint32_t COSET_MASK[6] = {0x27u, 0x27u, 0x55u, 0x1Bu, 0x01u, 0x55u};
+#ifndef G2048_FIXED_VARIANTS
+#define G2048_FIXED_VARIANTS 5      // (6 = the cross orbit too: twice the chunks to scan, measured 0.20 -> 0.245 ms)
+#endif
 template <int N> struct OwnVariants { static constexpr int COUNT = N == 4 ? 5 : 6; static constexpr int f0(int v) { return ORBIT_REPS[v]; } static constexpr int fc(int) { return 1; } };
 template <> struct OwnVariants<2> { static constexpr int COUNT = 1; static constexpr int f0(int) { return 0; } static constexpr int fc(int) { return 24; } };
 template <> struct OwnVariants<3> { static constexpr int COUNT = 7; static constexpr int f0(int v) { return 8 * v; } static constexpr int fc(int v) { return v < 6 ? 8 : 4; } };
 
 // which variants sum in 64-bit fixed point: the five four-cell orbits of n >= 4
-constexpr bool own_fixed(int n, int variant) { return n >= 4 && variant < 5; }
+constexpr bool own_fixed(int n, int variant) { return n >= 4 && variant < G2048_FIXED_VARIANTS; }
 constexpr uint32_t FIXED_SLOTS = OWN_SLOTS / 2;
 
 __device__ __forceinline__ Packed unpack4(const uint4& v) {
@@ -739,7 +753,7 @@ __device__ __forceinline__ Packed unpack4(const uint4& v) {
 // in 64-bit fixed point: dw * 2^S with S chosen from the step's largest |dw| so that 2^24 adds cannot overflow and a
 // dw 2^-14 times smaller than the largest is still exact; the flush converts back.  Half as many slots fit in LDS
 // (chunks of 16 384), the sums no longer depend on the order of the adds.
-template <int N, int F0, int FC, bool FB, bool FIXED>
+template <int N, int F0, int FC, bool FB, bool FIXED, uint32_t IMAGES>
 __device__ __forceinline__ void own_accum(const Packed& p, float dw, bool valid, float* acc, const Slice& sl, uint32_t& nhit, float* D,
                                           uint32_t* fb_hits, float scale) {
     constexpr int F = Shape<N>::F;
@@ -747,6 +761,7 @@ __device__ __forceinline__ void own_accum(const Packed& p, float dw, bool valid,
     if (FIXED) fixed = __float2ll_rn(dw * scale);
 #pragma unroll
     for (uint32_t g = 0; g < 8; ++g) {
+        if (!((IMAGES >> g) & 1u)) continue;
         uint32_t s[F];
         feature_slots<N>(d4_image(p, g), s);         // g is a constant after unrolling; unused slots are dead code
 #pragma unroll
@@ -776,6 +791,7 @@ __device__ __forceinline__ void own_run(float* acc, const Slice& s, const TdRecs
                                         float scale) {
     constexpr int F0 = OwnVariants<N>::f0(V), FC = OwnVariants<N>::fc(V), OWN_UNROLL = OwnUnroll<FC>::U;
     constexpr bool FIXED = own_fixed(N, V);
+    constexpr uint32_t IMAGES = N >= 4 ? COSET_MASK[V < 6 ? V : 0] : 0xFFu;
     uint32_t nhit = 0;
     {   // main records: this part's share of the lanes, OWN_UNROLL records per thread in flight; the loop bounds are
         // wave-uniform
@@ -793,7 +809,7 @@ __device__ __forceinline__ void own_run(float* acc, const Slice& s, const TdRecs
                 if (recs.unit) dw[u] = dw[u] != 0.0f ? 1.0f : 0.0f;
             }
 #pragma unroll
-            for (int u = 0; u < OWN_UNROLL; ++u) own_accum<N, F0, FC, FB, FIXED>(unpack4(st[u]), dw[u], dw[u] != 0.0f, acc, s, nhit, D, fb_hits, scale);
+            for (int u = 0; u < OWN_UNROLL; ++u) own_accum<N, F0, FC, FB, FIXED, IMAGES>(unpack4(st[u]), dw[u], dw[u] != 0.0f, acc, s, nhit, D, fb_hits, scale);
         }
     }
     {   // terminal queue
@@ -803,7 +819,7 @@ __device__ __forceinline__ void own_run(float* acc, const Slice& s, const TdRecs
             const uint32_t r = base0 + threadIdx.x;
             const bool ok = r < end;
             const uint32_t rr = ok ? r : end - 1;
-            own_accum<N, F0, FC, FB, FIXED>(ld_packed(recs.qstate, rr), recs.unit ? 1.0f : recs.qdw[rr], ok, acc, s, nhit, D, fb_hits, scale);
+            own_accum<N, F0, FC, FB, FIXED, IMAGES>(ld_packed(recs.qstate, rr), recs.unit ? 1.0f : recs.qdw[rr], ok, acc, s, nhit, D, fb_hits, scale);
         }
     }
     // load statistics for the planner: one counter bump per wave
@@ -832,7 +848,7 @@ __device__ __forceinline__ void own_dispatch(float* acc, const Slice& s, const T
 template <int N>
 __global__ __launch_bounds__(OWN_WG) void k_td_update_owner(float* dst, TdRecs recs, uint32_t B, const Slice* slices, uint32_t* hits) {
     __shared__ float acc[OWN_SLOTS];
-    __shared__ uint32_t fb_hits[32];
+    __shared__ uint32_t fb_hits[64];
     const Slice s = slices[blockIdx.x];
     const bool fixed = own_fixed(N, (int)s.variant);
     // fixed-point scale 2^S from the step's largest |dw| (< 2^e): 2^24 adds of at most 2^(e+S) stay below 2^62
@@ -847,11 +863,11 @@ __global__ __launch_bounds__(OWN_WG) void k_td_update_owner(float* dst, TdRecs r
     }
     const uint32_t words = fixed ? 2 * s.size : s.size;        // a fixed-point slot is two LDS words
     for (uint32_t j = threadIdx.x; j < words; j += OWN_WG) acc[j] = 0.0f;
-    if (threadIdx.x < 32) fb_hits[threadIdx.x] = 0;
+    if (threadIdx.x < 64) fb_hits[threadIdx.x] = 0;
     __syncthreads();
     own_dispatch<N, 0>(acc, s, recs, B, hits, dst, fb_hits, scale);
     __syncthreads();
-    if (threadIdx.x < 32 && fb_hits[threadIdx.x]) atomicAdd(&hits[s.chunk0 + threadIdx.x], fb_hits[threadIdx.x]);
+    if (threadIdx.x < 64 && fb_hits[threadIdx.x]) atomicAdd(&hits[s.chunk0 + threadIdx.x], fb_hits[threadIdx.x]);
     for (uint32_t j = threadIdx.x; j < s.size; j += OWN_WG) {
         float v;
         if (fixed)
@@ -872,15 +888,20 @@ __global__ __launch_bounds__(OWN_WG) void k_td_update_owner(float* dst, TdRecs r
 __global__ __launch_bounds__(WG) void k_apply_orbits(float* w, float* D, OrbitTable t) {
     const uint32_t K = blockIdx.x * WG + threadIdx.x;
     if (K >= t.total) return;
-    const float v = D[K];
-    if (v == 0.0f) return;
-    D[K] = 0.0f;
     uint32_t o = 0;
 #pragma unroll
     for (uint32_t j = 1; j < MAX_ORBITS; ++j)
         if (j < t.count && K >= t.o[j].base) o = j;
     const OrbitInfo& oi = t.o[o];
     const uint32_t k = K - oi.base;
+    float v = D[K];
+    if (oi.nstab == 1) {
+        if (v == 0.0f) return;
+        D[K] = 0.0f;
+    } else {            // symmetrise over the stabiliser; these (LDS-owned) orbit tables are cleared by the host afterwards
+        for (uint32_t s = 1; s < oi.nstab; ++s) v += D[oi.base + permute_digits(k, oi.sperm[s], oi.digits, oi.radix)];
+        if (v == 0.0f) return;
+    }
     for (uint32_t m = 0; m < oi.nmem; ++m) w[oi.off[m] + permute_digits(k, oi.perm[m], oi.digits, oi.radix)] += v;
 }
 
@@ -889,17 +910,26 @@ __global__ __launch_bounds__(WG) void k_apply_orbits(float* w, float* D, OrbitTa
 __global__ __launch_bounds__(WG) void k_apply_orbits_mean(float* w, float* S, float* C, OrbitTable t) {
     const uint32_t K = blockIdx.x * WG + threadIdx.x;
     if (K >= t.total) return;
-    const float cnt = C[K];
-    if (cnt == 0.0f) return;
-    const float v = S[K] / cnt;
-    S[K] = 0.0f;
-    C[K] = 0.0f;
     uint32_t o = 0;
 #pragma unroll
     for (uint32_t j = 1; j < MAX_ORBITS; ++j)
         if (j < t.count && K >= t.o[j].base) o = j;
     const OrbitInfo& oi = t.o[o];
     const uint32_t k = K - oi.base;
+    float cnt = C[K], sum = S[K];
+    if (oi.nstab == 1) {
+        if (cnt == 0.0f) return;
+        S[K] = 0.0f;
+        C[K] = 0.0f;
+    } else {
+        for (uint32_t s = 1; s < oi.nstab; ++s) {
+            const uint32_t j = oi.base + permute_digits(k, oi.sperm[s], oi.digits, oi.radix);
+            cnt += C[j];
+            sum += S[j];
+        }
+        if (cnt == 0.0f) return;
+    }
+    const float v = sum / cnt;
     for (uint32_t m = 0; m < oi.nmem; ++m) w[oi.off[m] + permute_digits(k, oi.perm[m], oi.digits, oi.radix)] += v;
 }
 
@@ -1023,6 +1053,7 @@ struct g2048_ctx {
     uint32_t n_slices = 0;
     uint32_t* hits = nullptr;           // adds per table chunk since the last re-plan (load statistics)
     uint32_t n_chunks = 0;
+    uint32_t owned_total = 0;       // D[0 .. owned_total): the LDS-owned orbit tables (cleared by the host after k_apply_orbits)
     uint32_t steps_since_plan = 0, replan_every = 8;     // the board distribution drifts with the games' age: follow it closely
     std::vector<double> load;           // smoothed adds per step per chunk
     float* D = nullptr;                 // per-orbit delta tables (n >= 4; mean rule: also the sums for n = 2, 3)
@@ -1206,6 +1237,52 @@ int find_orbits(g2048_ctx* c) {
             rep_of.push_back(i);
         }
     }
+    // stabiliser of every LDS-owned representative, and the check of the owner kernel's coset masks
+    for (uint32_t o = 0; o < T.count; ++o) {
+        OrbitInfo& oi = T.o[o];
+        oi.nstab = 1;
+        oi.sperm[0] = oi.perm[0];                                   // identity
+        if (oi.radix != 16u) continue;
+        if (o >= 6 || rep_of[o] != ORBIT_REPS[o]) return fail(c, G2048_ERR_STATE, "unexpected orbit structure");
+        c->owned_total = oi.base + oi.size;
+        const uint32_t nd = oi.digits;
+        uint32_t mine[NB][6];
+        for (int t = 0; t < NB; ++t) digits_of(host_feature_index<N>(boards[t], rep_of[o]), 16u, nd, mine[t]);
+        for (uint32_t g = 1; g < 8; ++g) {
+            uint32_t theirs[NB][6];
+            for (int t = 0; t < NB; ++t) digits_of(host_feature_index<N>(d4_image(boards[t], g), rep_of[o]), 16u, nd, theirs[t]);
+            uint32_t perm = 0, used = 0;
+            bool ok = true;
+            for (uint32_t pp = 0; pp < nd && ok; ++pp) {
+                int found = -1;
+                for (uint32_t q = 0; q < nd && found < 0; ++q) {
+                    if ((used >> q) & 1u) continue;
+                    bool same = true;
+                    for (int t = 0; t < NB && same; ++t) same = mine[t][pp] == theirs[t][q];
+                    if (same) found = (int)q;
+                }
+                if (found < 0) {
+                    ok = false;
+                } else {
+                    used |= 1u << found;
+                    perm |= (uint32_t)found << (3u * pp);
+                }
+            }
+            if (ok) oi.sperm[oi.nstab++] = perm;
+        }
+        for (int t = 0; t < NB; ++t) {
+            std::vector<uint32_t> all, folded;
+            for (uint32_t g = 0; g < 8; ++g) {
+                const uint32_t idx = host_feature_index<N>(d4_image(boards[t], g), rep_of[o]);
+                all.push_back(idx);
+                if ((COSET_MASK[o] >> g) & 1u)
+                    for (uint32_t st = 0; st < oi.nstab; ++st) folded.push_back(permute_digits(idx, oi.sperm[st], nd, 16u));
+            }
+            std::sort(all.begin(), all.end());
+            std::sort(folded.begin(), folded.end());
+            if (all != folded) return fail(c, G2048_ERR_STATE, "coset mask does not reproduce the 8 images");
+        }
+    }
     if (N == 6) {       // k_td_update_tail hard-codes the two f_6 representatives
         if (T.count != 8 || rep_of[6] != 21 || rep_of[7] != 22) return fail(c, G2048_ERR_STATE, "unexpected f_6 orbit structure");
     }
@@ -1279,7 +1356,8 @@ int build_slices(g2048_ctx* c) {
             double share = 1.0;
             if (c->n >= 4) {
                 const uint32_t rel = (chunks[k].dlo % (chunks[k].scan == 1.0 ? 65536u : 1048576u)) / chunks[k].size;
-                share = chunks[k].scan == 1.0 ? (rel == 0 ? 0.7 : rel == 1 ? 0.28 : 0.01) : ((rel & 1) == 0 && rel < 16 ? 0.12 : 0.001);
+                const uint32_t per16 = 65536u / chunks[k].size;       // chunks per value of the cross's leading nibble
+                share = chunks[k].scan == 1.0 ? (rel == 0 ? 0.7 : rel == 1 ? 0.28 : 0.01) : (rel % per16 == 0 && rel < 8 * per16 ? 0.12 : 0.001);
             }
             c->load[k] = 8.0 * c->B * share * (c->n == 2 ? 24 : c->n == 3 ? (chunks[k].size / 4096.0) : 1);
         }
@@ -1291,7 +1369,7 @@ int build_slices(g2048_ctx* c) {
     const double B = c->B;
     // which chunks get LDS workgroups: those with at least `thr` of their orbit's adds, and each orbit's busiest
     std::vector<char> in_lds(nc, 1);
-    std::vector<uint32_t> duty(nc, 0);      // fallback mask carried by a chunk
+    std::vector<uint64_t> duty(nc, 0);      // fallback mask carried by a chunk
     if (c->n >= 4 && c->B >= 4096)
         for (size_t k0 = 0; k0 < nc; k0 += chunks[k0].orb_chunks) {
             const size_t cnt = chunks[k0].orb_chunks;
@@ -1304,7 +1382,7 @@ int build_slices(g2048_ctx* c) {
             for (size_t j = k0; j < k0 + cnt; ++j)
                 if (j != best && c->load[j] < thr * orbit_total) {
                     in_lds[j] = 0;
-                    duty[best] |= 1u << (j - k0);
+                    duty[best] |= 1ull << (j - k0);
                 }
         }
     std::vector<double> cost(nc, 0.0);
@@ -1325,8 +1403,8 @@ int build_slices(g2048_ctx* c) {
         if (!in_lds[k]) continue;
         parts[k] = 1 + (uint32_t)((budget - n_lds) * cost[k] / total);
         for (uint32_t p = 0; p < parts[k]; ++p)
-            v.push_back(Slice{chunks[k].variant, chunks[k].tlo, chunks[k].size, chunks[k].dlo, p, parts[k], (uint32_t)k, duty[k],
-                              chunks[k].orb_tlo, chunks[k].orb_dlo, chunks[k].chunk0, chunks[k].size});
+            v.push_back(Slice{chunks[k].variant, chunks[k].tlo, chunks[k].size, chunks[k].dlo, p, parts[k], (uint32_t)k,
+                              chunks[k].orb_tlo, chunks[k].orb_dlo, chunks[k].chunk0, duty[k], chunks[k].size});
     }
     if (v.size() > MAX_SLICES) return fail(c, G2048_ERR_STATE, "LDS-owner plan too large");
     // longest-running workgroups first
@@ -1387,12 +1465,15 @@ int launch_td_step(g2048_ctx* c, float alpha, hipEvent_t ev = nullptr) {
         BY_N(c, (k_td_update_owner<N><<<c->n_slices, OWN_WG, 0, c->stream>>>(dst, recs, B, c->slices, c->hits)));
         if (c->n == 6) k_td_update_tail<6><<<tail_grid, OWN_WG, 0, c->stream>>>(c->D, recs, B, c->orbits.o[6].base, c->orbits.o[7].base);
         if (c->update_rule == 1) {
-            if (c->n >= 4)
+            if (c->n >= 4) {
                 k_apply_orbits_mean<<<grid_for(c->orbits.total), WG, 0, c->stream>>>(c->w, c->D, c->Dcnt, c->orbits);
-            else
+                HIP_TRY(c, hipMemsetAsync(c->D, 0, (size_t)c->owned_total * 4, c->stream));
+                HIP_TRY(c, hipMemsetAsync(c->Dcnt, 0, (size_t)c->owned_total * 4, c->stream));
+            } else
                 k_apply_flat_mean<<<grid_for(c->slots), WG, 0, c->stream>>>(c->w, c->D, c->Dcnt, (uint32_t)c->slots);
         } else if (c->n >= 4) {
             k_apply_orbits<<<grid_for(c->orbits.total), WG, 0, c->stream>>>(c->w, c->D, c->orbits);
+            HIP_TRY(c, hipMemsetAsync(c->D, 0, (size_t)c->owned_total * 4, c->stream));
         }
     } else {
         BY_N(c, (k_td_update<N><<<grid_for((uint64_t)B * 16), WG, 0, c->stream>>>(c->w, recs, B)));

@@ -132,6 +132,8 @@ def main():
     ap.add_argument('--rule', default='sum', choices=['sum', 'mean'],
                     help="how a step's records are applied: 'sum' = the reference's arithmetic (the metric); 'mean' = per-slot "
                          "mean (what QAgent uses for batched training; a second accumulation pass)")
+    ap.add_argument('--sync-at-one', action='store_true',
+                    help='with one rank, still create the process group and run the per-epoch delta all-reduce (exercises the RCCL path on a 1-GPU box)')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse on one GPU)')
     args = ap.parse_args()
 
@@ -143,9 +145,14 @@ def main():
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}')
 
     dist = None
-    if world > 1:
+    if world > 1 or args.sync_at_one:
         import torch
         import torch.distributed as dist
+        if world == 1:                                      # --sync-at-one without a launcher
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ.setdefault('MASTER_PORT', '29517')
+            os.environ.setdefault('RANK', '0')
+            os.environ.setdefault('WORLD_SIZE', '1')
         if args.backend == 'nccl':
             torch.cuda.set_device(local_rank)
             dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))   # RCCL over xGMI
@@ -168,7 +175,7 @@ def main():
     if args.rule == 'mean':
         eng.set_update_rule(1)
         alpha = args.alpha
-    sync = par.DeltaSync(eng, dist) if world > 1 else None
+    sync = par.DeltaSync(eng, dist) if dist else None
 
     def run(steps):
         done = 0
@@ -229,7 +236,7 @@ def main():
             'config': {'workload': f'BASELINE config 4: full TD(0) loop, {n}-tuple table ({eng.slots * 4} B), '
                                    f'{B} concurrent episodes per GPU, auto-reset',
                        'batch_per_gpu': B, 'n_tuple': n, 'alpha_effective': alpha, 'update_rule': args.rule,
-                       'parallelism': f'episodes sharded over {world} GPU(s)' + (f', weight-delta all-reduce every {args.epoch} steps' if world > 1 else '')},
+                       'parallelism': f'episodes sharded over {world} GPU(s)' + (f', weight-delta all-reduce every {args.epoch} steps' if sync else '')},
             'roofline': {'bound': 'hbm', 'kernel': 'k_td_update_owner' if dominant == 'k_td_update' else dominant, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          'algorithmic_bytes_per_launch': dom_bytes, 'ms_per_launch': dom_ms,

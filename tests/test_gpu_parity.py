@@ -291,6 +291,19 @@ def test_td_steps_batch_vs_oracle(n, mode):
     eng.close()
 
 
+@pytest.mark.parametrize('rule', ['sum', 'mean'])
+@pytest.mark.parametrize('B,n', [(3, 5), (1000, 4), (70001, 5), (1237, 6), (777, 3)])
+def test_td_ragged_lane_counts(B, n, rule):
+    """Lane counts that are not a multiple of the wave, the workgroup or the record-scan stride."""
+    eng = Engine(B, n=n, seed=300 + B)
+    eng.set_auto_reset(False)
+    eng.set_update_rule(1 if rule == 'mean' else 0)
+    eng.step_random(25)
+    for t in range(3):
+        helpers.check_td_step(eng, n, formulas.exact_alpha(n), formulas.weights(n, scale=2.0 ** -(5 + t)), rule=rule)
+    eng.close()
+
+
 @pytest.mark.parametrize('n', [2, 3, 4, 5, 6])
 def test_td_mean_rule_vs_oracle(n):
     """The optional per-slot mean rule (g2048_set_update_rule(1)) against its restatement in the oracle."""
