@@ -84,6 +84,7 @@ SIGNATURES = {
     'g2048_delta_apply': (c_int, [_P, _P]),
     'g2048_delta_device_ptr': (c_int, [_P, POINTER(_P)]),
     'g2048_td_steps_profiled': (c_int, [_P, c_float, c_uint32, POINTER(c_float), POINTER(c_float)]),
+    'g2048_debug_owner_plan': (c_int, [_P, _P, c_uint32, POINTER(c_uint32)]),
     'g2048_stream_handle': (c_int, [_P, POINTER(_P)]),
 }
 

@@ -471,6 +471,26 @@ __global__ __launch_bounds__(WG) void k_update_records(float* w, const uint4* st
 //                           (r_learning.py:240); dw1[i] == 0 means "no record" (first move of a game, finished lane);
 //   terminal records      : (this step's afterstate, -V(after) * alpha / F) for lanes whose game ended after the spawn
 //                           (r_learning.py:248) — rare, so they go to a compact queue (one atomic counter bump per wave).
+// variant v of table N covers features [f0(v), f0(v) + fc(v))
+// n >= 4: one variant per LDS-owned orbit, encoding the orbit's representative feature (outer line 0, inner line 1,
+// corner square 8, edge square 9, centre square 12, cross 17; find_orbits checks that these are the representatives)
+constexpr int ORBIT_REPS[6] = {0, 1, 8, 9, 12, 17};
+// images (bit g = d4_image g) that the owner kernel visits for each representative: one per coset of its stabiliser
+// (columns 0 / 1: up-down mirror; corner square and cross: transpose; edge square: left-right mirror; the centre square
+// is fixed by the whole group).  4 + 4 + 4 + 4 + 1 + 4 = 21 LDS adds per record instead of 48.  find_orbits verifies
+// these masks against the brute-force enumeration of all 8 images.
+constexpr uint32_t COSET_MASK[6] = {0x27u, 0x27u, 0x55u, 0x1Bu, 0x01u, 0x55u};
+#ifndef G2048_FIXED_VARIANTS
+#define G2048_FIXED_VARIANTS 5      // (6 = the cross orbit too: twice the chunks to scan, measured 0.20 -> 0.245 ms)
+#endif
+
+// the j-th visited image of orbit variant V
+constexpr uint32_t coset_rank(uint32_t mask, uint32_t g) {
+    uint32_t r = 0;
+    for (uint32_t b = 0; b < g; ++b) r += (mask >> b) & 1u;
+    return r;
+}
+
 struct TdRecs {
     const uint4* state1;    // prev[cur]
     float* dw1;             // [B]
@@ -481,7 +501,47 @@ struct TdRecs {
     uint32_t unit;          // 1: every record counts as dw = 1 (the counting pass of the per-slot mean rule)
     uint32_t* dwmax;        // float bits of the largest |dw| among this step's records (scale of the fixed-point sums)
     uint32_t* dwmax_next;   // next step's, zeroed by k_td_play
+    // n >= 4: the orbit indices of state1, written by k_td_play when the state was chosen (OrbitIdx below); null otherwise
+    const uint8_t* oidx;    // of this step's records
+    uint8_t* oidx_nxt;      // of the states chosen in this step (next step's records)
 };
+
+// Orbit indices of a record's state (n >= 4).  The LDS-owner workgroups of one orbit only need that orbit's table indices
+// of the images they visit (COSET_MASK: 4 per record, 1 for the centre square), not the board: k_td_play computes the 21
+// of them once per lane — where VALU is idle behind the table gathers — and every one of the ~28 chunk scans reads 8 + 4
+// bytes per record (indices + dw) instead of re-deriving them from the 16-byte packed state.  Orbit-major, so that a
+// scan is one contiguous stream:  [4][B] uint2 (four 16-bit indices: outer line, inner line, corner square, edge square)
+// | [B] uint4 (four 20-bit cross indices) | [B] uint16 (centre square).
+constexpr size_t OIDX_BYTES_PER_LANE = 4 * 8 + 16 + 2;
+struct OrbitIdx {
+    uint2* q;       // [4][B]
+    uint4* x;       // [B]
+    uint16_t* c;    // [B]
+};
+__host__ __device__ __forceinline__ OrbitIdx orbit_idx(const uint8_t* base, size_t B) {
+    uint8_t* b = const_cast<uint8_t*>(base);
+    return OrbitIdx{reinterpret_cast<uint2*>(b), reinterpret_cast<uint4*>(b + 32 * B), reinterpret_cast<uint16_t*>(b + 48 * B)};
+}
+
+template <int N>
+__device__ __forceinline__ void store_orbit_indices(uint8_t* base, uint32_t B, uint32_t i, const Packed& p) {
+    static_assert(N >= 4, "orbits exist for n >= 4");
+    constexpr int F = Shape<N>::F;
+    uint32_t idx[6][4] = {};
+#pragma unroll
+    for (uint32_t g = 0; g < 8; ++g) {
+        uint32_t s[F];
+        feature_slots<N>(d4_image(p, g), s);            // g is constant after unrolling; what no orbit visits is dead code
+#pragma unroll
+        for (int v = 0; v < (N == 4 ? 5 : 6); ++v)
+            if ((COSET_MASK[v] >> g) & 1u) idx[v][coset_rank(COSET_MASK[v], g)] = s[ORBIT_REPS[v]] - feature_offset(N, ORBIT_REPS[v]);
+    }
+    const OrbitIdx o = orbit_idx(base, B);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) o.q[(size_t)v * B + i] = make_uint2(idx[v][0] | idx[v][1] << 16, idx[v][2] | idx[v][3] << 16);
+    o.c[i] = (uint16_t)idx[4][0];
+    if (N >= 5) o.x[i] = make_uint4(idx[5][0], idx[5][1], idx[5][2], idx[5][3]);
+}
 
 __device__ __forceinline__ void push_terminal(const TdRecs& r, const Packed& state, float dw) {
     uint32_t slot = atomicAdd(r.qcount, 1u);        // the compiler folds the wave's increments into one atomic
@@ -573,6 +633,7 @@ __global__ __launch_bounds__(WG) void k_td_play(uint4* boards, int32_t* scores, 
                 score += reward;
                 Packed after = pack_board(ch.after);
                 st_packed(prev_nxt, i, after);
+                if constexpr (N >= 4) store_orbit_indices<N>(recs.oidx_nxt, B, i, after);
                 old_label = c.value;
                 fl |= HAS_PREV;
                 moved = true;
@@ -669,7 +730,7 @@ struct Slice {
     // is this workgroup's duty.  orb_tlo / orb_dlo / chunk0: first table slot, first D index, first hit counter of the orbit.
     uint32_t orb_tlo, orb_dlo, chunk0;
     uint64_t fb_mask;
-    uint32_t csize;         // slots per chunk of this orbit table (OWN_SLOTS, or OWN_SLOTS / 2 for the fixed-point four-cell orbits)
+    uint32_t cshift;        // log2 of the slots per chunk of this orbit table (OWN_SLOTS, or OWN_SLOTS / 2 for the fixed-point orbits)
 };
 
 // Symmetry orbits (n >= 4).  QAgent.update adds dw at f_i(g.x) for all 8 images g (r_learning.py:207-214).  Features
@@ -721,18 +782,7 @@ constexpr int OWN_WG = 1024;
 constexpr uint32_t OWN_SLOTS = 32768;      // 128 KiB of the CU's 160 KiB LDS
 template <int FC> struct OwnUnroll { static constexpr int U = FC == 1 ? 4 : 1; };   // records in flight per thread (loads issued together)
 
-// variant v of table N covers features [f0(v), f0(v) + fc(v))
-// n >= 4: one variant per LDS-owned orbit, encoding the orbit's representative feature (outer line 0, inner line 1,
-// corner square 8, edge square 9, centre square 12, cross 17; find_orbits checks that these are the representatives)
-constexpr int ORBIT_REPS[6] = {0, 1, 8, 9, 12, 17};
-// images (bit g = d4_image g) that the owner kernel visits for each representative: one per coset of its stabiliser
-// (columns 0 / 1: up-down mirror; corner square and cross: transpose; edge square: left-right mirror; the centre square
-// is fixed by the whole group).  4 + 4 + 4 + 4 + 1 + 4 = 21 LDS adds per record instead of 48.  find_orbits verifies
-// these masks against the brute-force enumeration of all 8 images.
-constexpr uint32_t COSET_MASK[6] = {0x27u, 0x27u, 0x55u, 0x1Bu, 0x01u, 0x55u};
-#ifndef G2048_FIXED_VARIANTS
-#define G2048_FIXED_VARIANTS 5      // (6 = the cross orbit too: twice the chunks to scan, measured 0.20 -> 0.245 ms)
-#endif
+// variant v of table N covers features [f0(v), f0(v) + fc(v)); n >= 4: the orbit representatives ORBIT_REPS
 template <int N> struct OwnVariants { static constexpr int COUNT = N == 4 ? 5 : 6; static constexpr int f0(int v) { return ORBIT_REPS[v]; } static constexpr int fc(int) { return 1; } };
 template <> struct OwnVariants<2> { static constexpr int COUNT = 1; static constexpr int f0(int) { return 0; } static constexpr int fc(int) { return 24; } };
 template <> struct OwnVariants<3> { static constexpr int COUNT = 7; static constexpr int f0(int v) { return 8 * v; } static constexpr int fc(int v) { return v < 6 ? 8 : 4; } };
@@ -748,6 +798,14 @@ __device__ __forceinline__ Packed unpack4(const uint4& v) {
     return q;
 }
 
+// dw * 2^S rounded to the nearest (even) integer, as a 64-bit two's complement number: adding 1.5 * 2^52 leaves exactly
+// that integer in the low mantissa bits of the double (|dw * 2^S| < 2^39 here).  Four instructions; the float -> int64
+// conversion of the compiler's runtime is fourteen.
+__device__ __forceinline__ long long to_fixed(float dw, double scale) {
+    constexpr double MAGIC = 6755399441055744.0;
+    return __double_as_longlong(fma((double)dw, scale, MAGIC)) - __double_as_longlong(MAGIC);
+}
+
 // FIXED: the four-cell orbits (n >= 4) take 40 of a record's 48 adds, and `ds_add_f32` manages 0.33 lane-adds per
 // cycle per CU against 4.1 for `ds_add_u64` (profiles/r01_lds_atomic_microbench.txt).  Their workgroups therefore sum
 // in 64-bit fixed point: dw * 2^S with S chosen from the step's largest |dw| so that 2^24 adds cannot overflow and a
@@ -758,7 +816,7 @@ __device__ __forceinline__ void own_accum(const Packed& p, float dw, bool valid,
                                           uint32_t* fb_hits, float scale) {
     constexpr int F = Shape<N>::F;
     long long fixed = 0;
-    if (FIXED) fixed = __float2ll_rn(dw * scale);
+    if (FIXED) fixed = to_fixed(dw, (double)scale);
 #pragma unroll
     for (uint32_t g = 0; g < 8; ++g) {
         if (!((IMAGES >> g) & 1u)) continue;
@@ -776,11 +834,38 @@ __device__ __forceinline__ void own_accum(const Packed& p, float dw, bool valid,
             }
             nhit += hit ? 1u : 0u;
             if (FB && valid && !hit) {
-                const uint32_t rel = s[f] - sl.orb_tlo, ch = rel / sl.csize;
+                const uint32_t rel = s[f] - sl.orb_tlo, ch = rel >> sl.cshift;
                 if ((sl.fb_mask >> ch) & 1u) {
                     __hip_atomic_fetch_add(&D[sl.orb_dlo + rel], dw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     atomicAdd(&fb_hits[ch], 1u);            // LDS counter, flushed once per workgroup
                 }
+            }
+        }
+    }
+}
+
+// the same accumulation from precomputed orbit indices (k_td_play's OrbitIdx records); idx are relative to the orbit table
+template <int NI, bool FB, bool FIXED>
+__device__ __forceinline__ void own_accum_idx(const uint32_t (&idx)[NI], float dw, bool valid, float* acc, const Slice& sl, uint32_t lo_rel,
+                                              uint32_t& nhit_wave, float* D, uint32_t* fb_hits, double scale) {
+    long long fixed = 0;
+    if (FIXED) fixed = to_fixed(dw, scale);
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const uint32_t rel = idx[j], local = rel - lo_rel;
+        const bool hit = valid && local < sl.size;
+        if (hit) {
+            if (FIXED)
+                atomicAdd(reinterpret_cast<unsigned long long*>(acc) + local, (unsigned long long)fixed);
+            else
+                atomicAdd(&acc[local], dw);
+        }
+        nhit_wave += (uint32_t)__popcll(__ballot(hit));         // scalar unit
+        if (FB && valid && !hit) {
+            const uint32_t ch = rel >> sl.cshift;
+            if ((sl.fb_mask >> ch) & 1u) {
+                __hip_atomic_fetch_add(&D[sl.orb_dlo + rel], dw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                atomicAdd(&fb_hits[ch], 1u);            // LDS counter, flushed once per workgroup
             }
         }
     }
@@ -792,8 +877,39 @@ __device__ __forceinline__ void own_run(float* acc, const Slice& s, const TdRecs
     constexpr int F0 = OwnVariants<N>::f0(V), FC = OwnVariants<N>::fc(V), OWN_UNROLL = OwnUnroll<FC>::U;
     constexpr bool FIXED = own_fixed(N, V);
     constexpr uint32_t IMAGES = N >= 4 ? COSET_MASK[V < 6 ? V : 0] : 0xFFu;
-    uint32_t nhit = 0;
-    {   // main records: this part's share of the lanes, OWN_UNROLL records per thread in flight; the loop bounds are
+    uint32_t nhit = 0, nhit_wave = 0;
+    if constexpr (N >= 4) {
+        // main records from their precomputed orbit indices: 8 B (cross: 16 B, centre square: 2 B) + dw per record
+        constexpr int NI = V == 4 ? 1 : 4, U = 4;
+        const OrbitIdx oi = orbit_idx(recs.oidx, B);
+        const uint32_t lo_rel = s.tlo - s.orb_tlo;
+        const uint32_t begin = (uint32_t)((uint64_t)B * s.part / s.nparts), end = (uint32_t)((uint64_t)B * (s.part + 1) / s.nparts);
+        for (uint32_t base0 = begin; base0 < end; base0 += OWN_WG * U) {
+            uint32_t idx[U][NI];
+            float dw[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t r = base0 + threadIdx.x + (uint32_t)u * OWN_WG;
+                const bool ok = r < end;
+                const uint32_t rr = ok ? r : end - 1;
+                if constexpr (V < 4) {
+                    const uint2 t = oi.q[(size_t)V * B + rr];
+                    idx[u][0] = t.x & 0xFFFFu; idx[u][1] = t.x >> 16; idx[u][2] = t.y & 0xFFFFu; idx[u][3] = t.y >> 16;
+                } else if constexpr (V == 4) {
+                    idx[u][0] = oi.c[rr];
+                } else {
+                    const uint4 t = oi.x[rr];
+                    idx[u][0] = t.x; idx[u][1] = t.y; idx[u][2] = t.z; idx[u][3] = t.w;
+                }
+                const float d = recs.dw1[rr];
+                dw[u] = ok ? d : 0.0f;
+                if (recs.unit) dw[u] = dw[u] != 0.0f ? 1.0f : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                own_accum_idx<NI, FB, FIXED>(idx[u], dw[u], dw[u] != 0.0f, acc, s, lo_rel, nhit_wave, D, fb_hits, (double)scale);
+        }
+    } else {   // main records: this part's share of the lanes, OWN_UNROLL records per thread in flight; the loop bounds are
         // wave-uniform
         const uint32_t begin = (uint32_t)((uint64_t)B * s.part / s.nparts), end = (uint32_t)((uint64_t)B * (s.part + 1) / s.nparts);
         for (uint32_t base0 = begin; base0 < end; base0 += OWN_WG * OWN_UNROLL) {
@@ -825,6 +941,7 @@ __device__ __forceinline__ void own_run(float* acc, const Slice& s, const TdRecs
     // load statistics for the planner: one counter bump per wave
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) nhit += __shfl_down(nhit, off);
+    nhit += nhit_wave;
     if ((threadIdx.x & 63) == 0 && nhit) atomicAdd(&hits[s.chunk], nhit);
 }
 
@@ -846,10 +963,12 @@ __device__ __forceinline__ void own_dispatch(float* acc, const Slice& s, const T
 
 // `dst` is the orbit table D (n >= 4) or the weight table itself (n = 2, 3)
 template <int N>
-__global__ __launch_bounds__(OWN_WG) void k_td_update_owner(float* dst, TdRecs recs, uint32_t B, const Slice* slices, uint32_t* hits) {
+__global__ __launch_bounds__(OWN_WG) void k_td_update_owner(float* dst, TdRecs recs, uint32_t B, const Slice* slices, uint32_t* hits,
+                                                            uint64_t* wg_clock) {
     __shared__ float acc[OWN_SLOTS];
     __shared__ uint32_t fb_hits[64];
     const Slice s = slices[blockIdx.x];
+    if (threadIdx.x == 0) wg_clock[2 * blockIdx.x] = wall_clock64();          // diagnostics: g2048_debug_owner_plan
     const bool fixed = own_fixed(N, (int)s.variant);
     // fixed-point scale 2^S from the step's largest |dw| (< 2^e): 2^24 adds of at most 2^(e+S) stay below 2^62
     float scale = 1.0f, inv_scale = 1.0f;
@@ -881,25 +1000,32 @@ __global__ __launch_bounds__(OWN_WG) void k_td_update_owner(float* dst, TdRecs r
                 __hip_atomic_fetch_add(&dst[s.dlo + j], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+    if (threadIdx.x == 0) wg_clock[2 * blockIdx.x + 1] = wall_clock64();
 }
 
 // D -> every member table of its orbit (plain read-modify-write: for one member the permutation is a bijection, and
 // members are different features, so no two threads touch the same slot), then D is cleared for the next step.
-__global__ __launch_bounds__(WG) void k_apply_orbits(float* w, float* D, OrbitTable t) {
+// The LDS-owned orbit tables [0, owned) are double-buffered (cur: this step's sums, oth: the next step's, cleared here;
+// a clear in place would race with the threads that read E[sigma(k)]; a memset between the steps costs a launch and, in
+// ROCclr, ~20 us of idle queue); the f_6 orbit tables behind them live in D and are cleared in place.
+__global__ __launch_bounds__(WG) void k_apply_orbits(float* w, float* D, const float* cur, float* oth, uint32_t owned, OrbitTable t) {
     const uint32_t K = blockIdx.x * WG + threadIdx.x;
     if (K >= t.total) return;
+    if (K < owned) oth[K] = 0.0f;
     uint32_t o = 0;
 #pragma unroll
     for (uint32_t j = 1; j < MAX_ORBITS; ++j)
         if (j < t.count && K >= t.o[j].base) o = j;
     const OrbitInfo& oi = t.o[o];
     const uint32_t k = K - oi.base;
-    float v = D[K];
-    if (oi.nstab == 1) {
+    float v;
+    if (K >= owned) {
+        v = D[K];
         if (v == 0.0f) return;
         D[K] = 0.0f;
-    } else {            // symmetrise over the stabiliser; these (LDS-owned) orbit tables are cleared by the host afterwards
-        for (uint32_t s = 1; s < oi.nstab; ++s) v += D[oi.base + permute_digits(k, oi.sperm[s], oi.digits, oi.radix)];
+    } else {            // symmetrise over the stabiliser
+        v = cur[K];
+        for (uint32_t s = 1; s < oi.nstab; ++s) v += cur[oi.base + permute_digits(k, oi.sperm[s], oi.digits, oi.radix)];
         if (v == 0.0f) return;
     }
     for (uint32_t m = 0; m < oi.nmem; ++m) w[oi.off[m] + permute_digits(k, oi.perm[m], oi.digits, oi.radix)] += v;
@@ -907,25 +1033,34 @@ __global__ __launch_bounds__(WG) void k_apply_orbits(float* w, float* D, OrbitTa
 
 // Per-slot mean rule (g2048_set_update_rule): S = sum of the dw that target a slot, C = how many did; the slot moves
 // by S / C.  S and C come from two runs of the same accumulation (the second with dw = 1).
-__global__ __launch_bounds__(WG) void k_apply_orbits_mean(float* w, float* S, float* C, OrbitTable t) {
+__global__ __launch_bounds__(WG) void k_apply_orbits_mean(float* w, float* S, float* C, const float* scur, const float* ccur, float* soth,
+                                                          float* coth, uint32_t owned, OrbitTable t) {
     const uint32_t K = blockIdx.x * WG + threadIdx.x;
     if (K >= t.total) return;
+    if (K < owned) {
+        soth[K] = 0.0f;
+        coth[K] = 0.0f;
+    }
     uint32_t o = 0;
 #pragma unroll
     for (uint32_t j = 1; j < MAX_ORBITS; ++j)
         if (j < t.count && K >= t.o[j].base) o = j;
     const OrbitInfo& oi = t.o[o];
     const uint32_t k = K - oi.base;
-    float cnt = C[K], sum = S[K];
-    if (oi.nstab == 1) {
+    float cnt, sum;
+    if (K >= owned) {
+        cnt = C[K];
+        sum = S[K];
         if (cnt == 0.0f) return;
         S[K] = 0.0f;
         C[K] = 0.0f;
     } else {
+        cnt = ccur[K];
+        sum = scur[K];
         for (uint32_t s = 1; s < oi.nstab; ++s) {
             const uint32_t j = oi.base + permute_digits(k, oi.sperm[s], oi.digits, oi.radix);
-            cnt += C[j];
-            sum += S[j];
+            cnt += ccur[j];
+            sum += scur[j];
         }
         if (cnt == 0.0f) return;
     }
@@ -1038,6 +1173,9 @@ struct g2048_ctx {
     int32_t* scores = nullptr;
     ulonglong2* rng = nullptr;
     uint4* prev[2] = {nullptr, nullptr};
+    uint8_t* oidx[2] = {nullptr, nullptr};      // orbit indices of prev[] (n >= 4)
+    uint64_t* wg_clock = nullptr;               // [MAX_SLICES][2] start / end clock of every owner workgroup (last launch)
+    std::vector<Slice> plan;                    // host copy of the slices in use
     float* label = nullptr;
     uint8_t* flags = nullptr;
     float* dw1 = nullptr;               // main record of every lane (0 = none)
@@ -1056,8 +1194,12 @@ struct g2048_ctx {
     uint32_t owned_total = 0;       // D[0 .. owned_total): the LDS-owned orbit tables (cleared by the host after k_apply_orbits)
     uint32_t steps_since_plan = 0, replan_every = 8;     // the board distribution drifts with the games' age: follow it closely
     std::vector<double> load;           // smoothed adds per step per chunk
+    std::vector<double> work;           // measured workgroup time x workgroups per chunk (clock ticks; 0 = not measured yet)
     float* D = nullptr;                 // per-orbit delta tables (n >= 4; mean rule: also the sums for n = 2, 3)
     float* Dcnt = nullptr;              // mean rule: how many adds each slot of D received
+    float* D2 = nullptr;                // second buffer of D[0 .. owned_total) and of Dcnt (n >= 4): see k_apply_orbits
+    float* Dcnt2 = nullptr;
+    uint32_t dpar = 0;                  // which buffer this step's LDS-owner sums go to
     int update_rule = 0;                // 0: add every dw (QAgent.update), 1: per-slot mean
     OrbitTable orbits = {};
     int update_mode = 1;                // 1: LDS-owner update (default), 0: global fp32 atomics
@@ -1296,6 +1438,7 @@ int find_orbits(g2048_ctx* c) {
 // boards put almost every add into the low half of each table, a trained agent's boards do not.
 constexpr uint32_t MAX_SLICES = 1024;
 constexpr uint32_t WG_BUDGET = 250;
+constexpr uint32_t XCDS = 8, CUS_PER_XCD = 32;
 
 struct ChunkInfo {
     uint32_t variant, tlo, size, dlo;
@@ -1334,8 +1477,11 @@ int build_slices(g2048_ctx* c) {
             if (rc) return rc;
             if ((rc = dalloc(c, &c->D, c->orbits.total))) return rc;
             HIP_TRY(c, hipMemset(c->D, 0, (size_t)c->orbits.total * 4));
+            if ((rc = dalloc(c, &c->D2, c->owned_total))) return rc;
+            HIP_TRY(c, hipMemset(c->D2, 0, (size_t)c->owned_total * 4));
         }
         if (int rc = dalloc(c, &c->slices, MAX_SLICES)) return rc;
+        if (int rc = dalloc(c, &c->wg_clock, 2 * MAX_SLICES)) return rc;
     }
     const std::vector<ChunkInfo> chunks = table_chunks(c);
     const size_t nc = chunks.size();
@@ -1362,7 +1508,7 @@ int build_slices(g2048_ctx* c) {
             c->load[k] = 8.0 * c->B * share * (c->n == 2 ? 24 : c->n == 3 ? (chunks[k].size / 4096.0) : 1);
         }
     }
-    double add_cost = 1.5, thr = 0.01, fixed_ratio = 0.25;
+    double add_cost = 3.0, thr = 0.01, fixed_ratio = 0.25;
     if (const char* e = getenv("G2048_PLAN_FIXEDRATIO")) fixed_ratio = atof(e);
     if (const char* e = getenv("G2048_PLAN_ADDCOST")) add_cost = atof(e);      // (experiments)
     if (const char* e = getenv("G2048_PLAN_THR")) thr = atof(e);
@@ -1388,6 +1534,7 @@ int build_slices(g2048_ctx* c) {
     std::vector<double> cost(nc, 0.0);
     double total = 0;
     size_t n_lds = 0;
+    (void)total;
     for (size_t k = 0; k < nc; ++k)
         if (in_lds[k]) {
             // an add costs ~12x less where the sums are 64-bit fixed point (ds_add_u64) than where they are fp32 (ds_add_f32)
@@ -1396,20 +1543,73 @@ int build_slices(g2048_ctx* c) {
             total += cost[k];
             ++n_lds;
         }
-    const uint32_t budget = c->B < (1u << 14) ? (uint32_t)n_lds : (WG_BUDGET > n_lds ? WG_BUDGET : (uint32_t)n_lds);
+    // Feedback: where the last launches were timed (per-workgroup clocks, see replan), a chunk's cost is its measured
+    // work; chunks without a measurement (they had no workgroup yet) keep the model's cost, scaled to the same unit.
+    bool use_work = c->work.size() == nc && c->n >= 4;
+    if (const char* e = getenv("G2048_PLAN_FEEDBACK")) use_work = use_work && atoi(e) != 0;
+    if (use_work) {
+        double measured = 0, modelled = 0;
+        for (size_t k = 0; k < nc; ++k)
+            if (in_lds[k] && c->work[k] > 0) {
+                measured += c->work[k];
+                modelled += cost[k];
+            }
+        if (measured > 0 && modelled > 0) {
+            total = 0;
+            for (size_t k = 0; k < nc; ++k)
+                if (in_lds[k]) {
+                    cost[k] = c->work[k] > 0 ? c->work[k] : cost[k] * measured / modelled;
+                    total += cost[k];
+                }
+        }
+    }
     std::vector<Slice> v;
     std::vector<uint32_t> parts(nc, 0);
-    for (size_t k = 0; k < nc; ++k) {
-        if (!in_lds[k]) continue;
-        parts[k] = 1 + (uint32_t)((budget - n_lds) * cost[k] / total);
-        for (uint32_t p = 0; p < parts[k]; ++p)
-            v.push_back(Slice{chunks[k].variant, chunks[k].tlo, chunks[k].size, chunks[k].dlo, p, parts[k], (uint32_t)k,
-                              chunks[k].orb_tlo, chunks[k].orb_dlo, chunks[k].chunk0, duty[k], chunks[k].size});
+    auto slice_of = [&](size_t k, uint32_t p, uint32_t np) {
+        return Slice{chunks[k].variant, chunks[k].tlo, chunks[k].size, chunks[k].dlo, p, np, (uint32_t)k,
+                     chunks[k].orb_tlo, chunks[k].orb_dlo, chunks[k].chunk0, duty[k], chunks[k].size >= OWN_SLOTS ? 15u : 14u};
+    };
+    // (experiment, off by default: G2048_PLAN_XCD=1 — see below)
+    bool xcd_plan = false;
+    if (const char* e = getenv("G2048_PLAN_XCD")) xcd_plan = atoi(e) != 0 && c->n >= 4 && c->B >= (1u << 17) && n_lds <= CUS_PER_XCD;
+    if (xcd_plan) {
+        // XCD-resident scan.  Workgroup i runs on XCD i % 8 and every XCD has its own 4 MB L2.  The records are cut into 8
+        // ranges (2^20 lanes: 2.6 MB each); range x is scanned only by the workgroups of XCD x — one set of chunks per
+        // XCD, m_k workgroups for chunk k in each — so a range is fetched into its L2 once and every further scan of it
+        // hits there, instead of all ~28 chunk scans of all records going out to the fabric.
+        for (size_t k = 0; k < nc; ++k) parts[k] = in_lds[k] ? 1 : 0;
+        for (size_t extra = n_lds; extra < CUS_PER_XCD; ++extra) {          // greedy: the slowest workgroup gets help
+            size_t worst = nc;
+            for (size_t k = 0; k < nc; ++k)
+                if (in_lds[k] && (worst == nc || cost[k] / parts[k] > cost[worst] / parts[worst])) worst = k;
+            ++parts[worst];
+        }
+        std::vector<std::pair<size_t, uint32_t>> per_xcd;                   // (chunk, j) of one XCD, longest-running first
+        for (size_t k = 0; k < nc; ++k)
+            for (uint32_t j = 0; j < parts[k]; ++j) per_xcd.push_back({k, j});
+        std::stable_sort(per_xcd.begin(), per_xcd.end(), [&](const std::pair<size_t, uint32_t>& a, const std::pair<size_t, uint32_t>& b) {
+            return cost[a.first] / parts[a.first] > cost[b.first] / parts[b.first];
+        });
+        for (const auto& kj : per_xcd)
+            for (uint32_t x = 0; x < XCDS; ++x)
+                v.push_back(slice_of(kj.first, x * parts[kj.first] + kj.second, XCDS * parts[kj.first]));
+    } else {
+        const uint32_t budget = c->B < (1u << 14) ? (uint32_t)n_lds : (WG_BUDGET > n_lds ? WG_BUDGET : (uint32_t)n_lds);
+        for (size_t k = 0; k < nc; ++k) parts[k] = in_lds[k] ? 1 : 0;
+        for (size_t extra = n_lds; extra < budget; ++extra) {               // greedy: the slowest workgroup gets help
+            size_t worst = nc;
+            for (size_t k = 0; k < nc; ++k)
+                if (in_lds[k] && (worst == nc || cost[k] / parts[k] > cost[worst] / parts[worst])) worst = k;
+            ++parts[worst];
+        }
+        for (size_t k = 0; k < nc; ++k)
+            for (uint32_t p = 0; p < parts[k]; ++p) v.push_back(slice_of(k, p, parts[k]));
+        // longest-running workgroups first
+        std::stable_sort(v.begin(), v.end(), [&](const Slice& a, const Slice& b) { return cost[a.chunk] / a.nparts > cost[b.chunk] / b.nparts; });
     }
     if (v.size() > MAX_SLICES) return fail(c, G2048_ERR_STATE, "LDS-owner plan too large");
-    // longest-running workgroups first
-    std::stable_sort(v.begin(), v.end(), [&](const Slice& a, const Slice& b) { return cost[a.chunk] / a.nparts > cost[b.chunk] / b.nparts; });
     c->n_slices = (uint32_t)v.size();
+    c->plan = v;
     if (getenv("G2048_DEBUG_PLAN")) {
         fprintf(stderr, "[g2048 plan] %zu workgroups over %zu chunks; (chunk:load/parts)", v.size(), nc);
         for (size_t k = 0; k < nc; ++k) fprintf(stderr, " %zu:%.3f/%u", k, c->load[k] / (8.0 * B), parts[k]);
@@ -1428,6 +1628,30 @@ int replan(g2048_ctx* c) {
     if (int rc = d2h(c, h.data(), c->hits, h.size() * 4)) return rc;
     HIP_TRY(c, hipMemsetAsync(c->hits, 0, h.size() * 4, c->stream));
     for (size_t k = 0; k < h.size(); ++k) c->load[k] = 0.5 * c->load[k] + 0.5 * (double)h[k] / c->steps_since_plan;
+    // the last launch's workgroup clocks: work of a chunk = (mean duration - fixed part) x its workgroups
+    if (c->plan.size() == c->n_slices && c->n_slices) {
+        std::vector<uint64_t> clk(2 * (size_t)c->n_slices);
+        if (int rc = d2h(c, clk.data(), c->wg_clock, clk.size() * 8)) return rc;
+        const double fixed_ticks = 300.0;                   // LDS clear + flush, ~3 us of the 100 MHz clock
+        std::vector<double> sum(c->n_chunks, 0.0);
+        std::vector<uint32_t> cnt(c->n_chunks, 0);
+        for (uint32_t i = 0; i < c->n_slices; ++i) {
+            const uint64_t a = clk[2 * i], b = clk[2 * i + 1];
+            if (b <= a || b - a > 100000000ull || c->plan[i].chunk >= c->n_chunks) continue;      // (never launched / garbage)
+            sum[c->plan[i].chunk] += (double)(b - a);
+            ++cnt[c->plan[i].chunk];
+        }
+        if (c->work.size() != c->n_chunks) c->work.assign(c->n_chunks, 0.0);
+        for (uint32_t k = 0; k < c->n_chunks; ++k) {
+            if (!cnt[k]) {
+                c->work[k] = 0.0;                           // no workgroup: back to the model until it has one
+                continue;
+            }
+            const double mean = sum[k] / cnt[k];
+            const double w = (mean > fixed_ticks + 50.0 ? mean - fixed_ticks : 50.0) * cnt[k];
+            c->work[k] = c->work[k] > 0 ? 0.5 * c->work[k] + 0.5 * w : w;
+        }
+    }
     return build_slices(c);
 }
 
@@ -1446,6 +1670,8 @@ int launch_td_step(g2048_ctx* c, float alpha, hipEvent_t ev = nullptr) {
     recs.dwmax = c->qcount + 2 + c->step_parity;
     recs.dwmax_next = c->qcount + 2 + (c->step_parity ^ 1u);
     recs.unit = 0;
+    recs.oidx = c->oidx[c->cur];
+    recs.oidx_nxt = c->oidx[c->cur ^ 1];
     BY_N(c, (k_td_play<N><<<grid_for(B), WG, 0, c->stream>>>(c->boards, c->scores, c->rng, pn, c->label, c->flags, B, c->w, alpha, recs,
                                                              c->auto_reset, c->stats, c->last_move, c->log)));
     if (ev) (void)hipEventRecord(ev, c->stream);
@@ -1455,26 +1681,31 @@ int launch_td_step(g2048_ctx* c, float alpha, hipEvent_t ev = nullptr) {
         ++c->steps_since_plan;
         const uint32_t tail_grid = B >= (1u << 16) ? 512 : 16;
         recs.unit = 0;
+        // n >= 4: the LDS-owned orbit tables are double-buffered (k_apply_orbits clears the other one for the next step)
+        const bool alt = c->n >= 4 && c->dpar;
+        float* Dcur = alt ? c->D2 : c->D;
+        float* Doth = alt ? c->D : c->D2;
+        float* Ccur = alt ? c->Dcnt2 : c->Dcnt;
+        float* Coth = alt ? c->Dcnt : c->Dcnt2;
         if (c->update_rule == 1) {      // counting pass: the same accumulation with dw = 1, into Dcnt
             TdRecs ones = recs;
             ones.unit = 1;
-            BY_N(c, (k_td_update_owner<N><<<c->n_slices, OWN_WG, 0, c->stream>>>(c->Dcnt, ones, B, c->slices, c->hits)));
+            BY_N(c, (k_td_update_owner<N><<<c->n_slices, OWN_WG, 0, c->stream>>>(Ccur, ones, B, c->slices, c->hits, c->wg_clock)));
             if (c->n == 6) k_td_update_tail<6><<<tail_grid, OWN_WG, 0, c->stream>>>(c->Dcnt, ones, B, c->orbits.o[6].base, c->orbits.o[7].base);
         }
-        float* dst = (c->n >= 4 || c->update_rule == 1) ? c->D : c->w;
-        BY_N(c, (k_td_update_owner<N><<<c->n_slices, OWN_WG, 0, c->stream>>>(dst, recs, B, c->slices, c->hits)));
+        float* dst = c->n >= 4 ? Dcur : (c->update_rule == 1 ? c->D : c->w);
+        BY_N(c, (k_td_update_owner<N><<<c->n_slices, OWN_WG, 0, c->stream>>>(dst, recs, B, c->slices, c->hits, c->wg_clock)));
         if (c->n == 6) k_td_update_tail<6><<<tail_grid, OWN_WG, 0, c->stream>>>(c->D, recs, B, c->orbits.o[6].base, c->orbits.o[7].base);
         if (c->update_rule == 1) {
-            if (c->n >= 4) {
-                k_apply_orbits_mean<<<grid_for(c->orbits.total), WG, 0, c->stream>>>(c->w, c->D, c->Dcnt, c->orbits);
-                HIP_TRY(c, hipMemsetAsync(c->D, 0, (size_t)c->owned_total * 4, c->stream));
-                HIP_TRY(c, hipMemsetAsync(c->Dcnt, 0, (size_t)c->owned_total * 4, c->stream));
-            } else
+            if (c->n >= 4)
+                k_apply_orbits_mean<<<grid_for(c->orbits.total), WG, 0, c->stream>>>(c->w, c->D, c->Dcnt, Dcur, Ccur, Doth, Coth, c->owned_total,
+                                                                                        c->orbits);
+            else
                 k_apply_flat_mean<<<grid_for(c->slots), WG, 0, c->stream>>>(c->w, c->D, c->Dcnt, (uint32_t)c->slots);
         } else if (c->n >= 4) {
-            k_apply_orbits<<<grid_for(c->orbits.total), WG, 0, c->stream>>>(c->w, c->D, c->orbits);
-            HIP_TRY(c, hipMemsetAsync(c->D, 0, (size_t)c->owned_total * 4, c->stream));
+            k_apply_orbits<<<grid_for(c->orbits.total), WG, 0, c->stream>>>(c->w, c->D, Dcur, Doth, c->owned_total, c->orbits);
         }
+        if (c->n >= 4) c->dpar ^= 1u;
     } else {
         BY_N(c, (k_td_update<N><<<grid_for((uint64_t)B * 16), WG, 0, c->stream>>>(c->w, recs, B)));
     }
@@ -1550,8 +1781,8 @@ int g2048_destroy(g2048_ctx* c) {
     if (!c) return G2048_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void* bufs[] = {c->log.moves, c->log.start, c->log.meta, c->boards, c->scores, c->rng, c->prev[0], c->prev[1], c->label, c->flags, c->dw1, c->qstate,
-                    c->qdw,    c->qcount, c->last_move, c->w,      c->w0,  c->delta,   c->stats,   c->scratch, c->slices, c->hits, c->D, c->Dcnt};
+    void* bufs[] = {c->log.moves, c->log.start, c->log.meta, c->boards, c->scores, c->rng, c->prev[0], c->prev[1], c->oidx[0], c->oidx[1], c->label, c->flags, c->dw1, c->qstate,
+                    c->qdw,    c->qcount, c->last_move, c->w,      c->w0,  c->delta,   c->stats,   c->scratch, c->slices, c->hits, c->D, c->Dcnt, c->D2, c->Dcnt2, c->wg_clock};
     for (void* p : bufs)
         if (p && (p != (void*)c->w || c->owns_table)) (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -1598,6 +1829,7 @@ static int create_impl(int device, uint32_t batch, int n_tuple, uint64_t seed, u
         (rc = dalloc(c, &c->qcount, 4)) || (rc = dalloc(c, &c->last_move, B)) ||
         (rc = dalloc(c, &c->stats, 1)))
         return bail(rc);
+    if (n_tuple >= 4 && ((rc = dalloc(c, &c->oidx[0], OIDX_BYTES_PER_LANE * B)) || (rc = dalloc(c, &c->oidx[1], OIDX_BYTES_PER_LANE * B)))) return bail(rc);
     if (parent) {
         c->w = parent->w;
         c->owns_table = false;
@@ -1941,6 +2173,14 @@ int g2048_set_update_rule(g2048_ctx* c, int rule) {
             if ((rc = dalloc(c, &c->Dcnt, count))) return rc;
             HIP_TRY(c, hipMemset(c->Dcnt, 0, count * 4));
         }
+        if (c->n >= 4 && !c->Dcnt2) {
+            if ((rc = dalloc(c, &c->Dcnt2, c->owned_total))) return rc;
+            HIP_TRY(c, hipMemset(c->Dcnt2, 0, (size_t)c->owned_total * 4));
+        }
+        if (c->n >= 4 && c->update_rule == 0) {     // steps under the sum rule leave the count buffers alone: start clean
+            HIP_TRY(c, hipMemsetAsync(c->Dcnt, 0, (size_t)c->owned_total * 4, c->stream));
+            HIP_TRY(c, hipMemsetAsync(c->Dcnt2, 0, (size_t)c->owned_total * 4, c->stream));
+        }
     }
     c->update_rule = rule;
     return G2048_OK;
@@ -1970,6 +2210,27 @@ int g2048_td_steps_profiled(g2048_ctx* c, float alpha, uint32_t nsteps, float* m
     *ms_play = nsteps ? (float)(tp / nsteps) : 0.0f;
     *ms_update = nsteps ? (float)(tu / nsteps) : 0.0f;
     return launched(c, "k_td_play/k_td_update");
+}
+
+int g2048_debug_owner_plan(g2048_ctx* c, uint64_t* out, uint32_t capacity, uint32_t* count) {
+    if (!c || !out || !count) return c ? fail(c, G2048_ERR_ARG, "null buffer") : G2048_ERR_ARG;
+    NEED_TABLE(c);
+    if (int rc = bind(c)) return rc;
+    const uint32_t n = c->n_slices < capacity ? c->n_slices : capacity;
+    std::vector<uint64_t> clk(2 * (size_t)c->n_slices);
+    if (!clk.empty())
+        if (int rc = d2h(c, clk.data(), c->wg_clock, clk.size() * 8)) return rc;
+    for (uint32_t i = 0; i < n; ++i) {
+        const Slice& s = c->plan[i];
+        out[6 * i + 0] = s.variant;
+        out[6 * i + 1] = s.chunk;
+        out[6 * i + 2] = s.part;
+        out[6 * i + 3] = s.nparts;
+        out[6 * i + 4] = clk[2 * i];
+        out[6 * i + 5] = clk[2 * i + 1];
+    }
+    *count = n;
+    return G2048_OK;
 }
 
 int g2048_get_last_move(g2048_ctx* c, uint16_t* out) {

@@ -271,6 +271,13 @@ class Engine:
         self._c(self.lib.g2048_delta_device_ptr(self.ctx, ctypes.byref(p)))
         return p.value
 
+    def debug_owner_plan(self):
+        """[(variant, chunk, part, nparts, start_clock, end_clock)] of the last LDS-owner launch (100 MHz clock)."""
+        out = np.zeros((1024, 6), np.uint64)
+        n = ctypes.c_uint32(0)
+        self._c(self.lib.g2048_debug_owner_plan(self.ctx, _buf(out), 1024, ctypes.byref(n)))
+        return out[:n.value]
+
     def td_steps_profiled(self, alpha, nsteps):
         """(ms per k_td_play launch, ms per k_td_update launch), HIP events on the context's stream."""
         a, b = ctypes.c_float(), ctypes.c_float()

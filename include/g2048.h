@@ -133,6 +133,11 @@ int g2048_set_update_rule(g2048_ctx* ctx, int rule);
 /* the same, with HIP events around each of the step's two kernels (synchronises every step): average
  * milliseconds per launch of k_td_play and k_td_update, for the roofline line of bench.py */
 int g2048_td_steps_profiled(g2048_ctx* ctx, float alpha, uint32_t nsteps, float* ms_play, float* ms_update);
+
+/* Diagnostics of the LDS-owner update (update mode 1): for each workgroup of the current plan six words
+ * {orbit variant, chunk, part, nparts, start clock, end clock} of its last launch (clock: 100 MHz constant counter).
+ * No reference counterpart. */
+int g2048_debug_owner_plan(g2048_ctx* ctx, uint64_t* out, uint32_t capacity, uint32_t* count);
 /* what every lane did in the latest TD step — the entries Game.moves / Game.tiles get in QAgent.episode
  * (r_learning.py:244, game_logic.py:121): bits 0-1 direction, bit 2 a move was made, bits 4-7 cell (4*r + c) of
  * the new tile, bits 8-9 the new tile (1 or 2), bit 10 a tile was placed, bit 11 the game ended on this step. */
