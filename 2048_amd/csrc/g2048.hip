@@ -1175,6 +1175,10 @@ struct g2048_ctx {
     uint4* prev[2] = {nullptr, nullptr};
     uint8_t* oidx[2] = {nullptr, nullptr};      // orbit indices of prev[] (n >= 4)
     uint64_t* wg_clock = nullptr;               // [MAX_SLICES][2] start / end clock of every owner workgroup (last launch)
+    uint8_t* statbuf = nullptr;                 // one allocation: hit counters | workgroup clocks (one copy reads both back)
+    uint8_t* h_stat = nullptr;                  // pinned host mirrors: statbuf, and the staging of the slices
+    Slice* h_slices = nullptr;
+    std::vector<uint32_t> hits_seen;            // the counters are cumulative (mod 2^32); what the last readback saw
     std::vector<Slice> plan;                    // host copy of the slices in use
     float* label = nullptr;
     uint8_t* flags = nullptr;
@@ -1436,7 +1440,8 @@ int find_orbits(g2048_ctx* c) {
 // the records; the ~250 workgroups (one 128 KiB workgroup per CU) are handed out in proportion to each chunk's cost =
 // scanning the records + its measured adds per step (hit counters, read back every `replan_every` steps): young
 // boards put almost every add into the low half of each table, a trained agent's boards do not.
-constexpr uint32_t MAX_SLICES = 1024;
+constexpr uint32_t MAX_SLICES = 1024, HITS_CAP = 128;
+constexpr size_t STAT_BYTES = HITS_CAP * 4 + 2 * MAX_SLICES * 8;
 constexpr uint32_t WG_BUDGET = 250;
 constexpr uint32_t XCDS = 8, CUS_PER_XCD = 32;
 
@@ -1481,22 +1486,27 @@ int build_slices(g2048_ctx* c) {
             HIP_TRY(c, hipMemset(c->D2, 0, (size_t)c->owned_total * 4));
         }
         if (int rc = dalloc(c, &c->slices, MAX_SLICES)) return rc;
-        if (int rc = dalloc(c, &c->wg_clock, 2 * MAX_SLICES)) return rc;
+        if (int rc = dalloc(c, &c->statbuf, STAT_BYTES)) return rc;
+        HIP_TRY(c, hipMemset(c->statbuf, 0, STAT_BYTES));
+        c->hits = reinterpret_cast<uint32_t*>(c->statbuf);
+        c->wg_clock = reinterpret_cast<uint64_t*>(c->statbuf + HITS_CAP * 4);
+        HIP_TRY(c, hipHostMalloc((void**)&c->h_stat, STAT_BYTES, hipHostMallocDefault));
+        HIP_TRY(c, hipHostMalloc((void**)&c->h_slices, MAX_SLICES * sizeof(Slice), hipHostMallocDefault));
     }
     const std::vector<ChunkInfo> chunks = table_chunks(c);
     const size_t nc = chunks.size();
     if (nc == 0) return fail(c, G2048_ERR_STATE, "unexpected orbit structure");
-    if (!c->hits && getenv("G2048_DEBUG_PLAN"))
+    if (nc > HITS_CAP) return fail(c, G2048_ERR_STATE, "more chunks than hit counters");
+    if (!c->n_chunks && getenv("G2048_DEBUG_PLAN"))
         for (uint32_t o = 0; o < c->orbits.count; ++o) {
             const OrbitInfo& oi = c->orbits.o[o];
             fprintf(stderr, "[g2048 orbit %u] base %u size %u members:", o, oi.base, oi.size);
             for (uint32_t m = 0; m < oi.nmem; ++m) fprintf(stderr, " (slot %u perm %06o)", oi.off[m], oi.perm[m]);
             fprintf(stderr, "\n");
         }
-    if (!c->hits) {
-        if (int rc = dalloc(c, &c->hits, nc)) return rc;
-        HIP_TRY(c, hipMemset(c->hits, 0, nc * 4));
+    if (!c->n_chunks) {
         c->n_chunks = (uint32_t)nc;
+        c->hits_seen.assign(nc, 0u);
         c->load.assign(nc, 0.0);
         for (size_t k = 0; k < nc; ++k) {       // fresh games only touch small tiles: the low chunk of every table
             double share = 1.0;
@@ -1615,8 +1625,10 @@ int build_slices(g2048_ctx* c) {
         for (size_t k = 0; k < nc; ++k) fprintf(stderr, " %zu:%.3f/%u", k, c->load[k] / (8.0 * B), parts[k]);
         fprintf(stderr, "\n");
     }
-    HIP_TRY(c, hipMemcpyAsync(c->slices, v.data(), v.size() * sizeof(Slice), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    // pinned staging, no wait: the copy is ordered before the next launch, and the staging is not rewritten before the
+    // next replan's readback has synchronised the stream
+    memcpy(c->h_slices, v.data(), v.size() * sizeof(Slice));
+    HIP_TRY(c, hipMemcpyAsync(c->slices, c->h_slices, v.size() * sizeof(Slice), hipMemcpyHostToDevice, c->stream));
     c->steps_since_plan = 0;
     return G2048_OK;
 }
@@ -1624,14 +1636,18 @@ int build_slices(g2048_ctx* c) {
 // read the hit counters, fold them into the smoothed load and rebuild the plan (a few tens of microseconds)
 int replan(g2048_ctx* c) {
     if (c->n < 4 || c->n_chunks == 0 || c->steps_since_plan == 0) return G2048_OK;
-    std::vector<uint32_t> h(c->n_chunks);
-    if (int rc = d2h(c, h.data(), c->hits, h.size() * 4)) return rc;
-    HIP_TRY(c, hipMemsetAsync(c->hits, 0, h.size() * 4, c->stream));
-    for (size_t k = 0; k < h.size(); ++k) c->load[k] = 0.5 * c->load[k] + 0.5 * (double)h[k] / c->steps_since_plan;
+    // one copy into pinned memory brings the hit counters and the workgroup clocks; the only wait of the replan
+    HIP_TRY(c, hipMemcpyAsync(c->h_stat, c->statbuf, STAT_BYTES, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const uint32_t* h = reinterpret_cast<const uint32_t*>(c->h_stat);
+    for (size_t k = 0; k < c->n_chunks; ++k) {
+        const uint32_t fresh = h[k] - c->hits_seen[k];          // cumulative counters, modulo 2^32
+        c->hits_seen[k] = h[k];
+        c->load[k] = 0.5 * c->load[k] + 0.5 * (double)fresh / c->steps_since_plan;
+    }
     // the last launch's workgroup clocks: work of a chunk = (mean duration - fixed part) x its workgroups
     if (c->plan.size() == c->n_slices && c->n_slices) {
-        std::vector<uint64_t> clk(2 * (size_t)c->n_slices);
-        if (int rc = d2h(c, clk.data(), c->wg_clock, clk.size() * 8)) return rc;
+        const uint64_t* clk = reinterpret_cast<const uint64_t*>(c->h_stat + HITS_CAP * 4);
         const double fixed_ticks = 300.0;                   // LDS clear + flush, ~3 us of the 100 MHz clock
         std::vector<double> sum(c->n_chunks, 0.0);
         std::vector<uint32_t> cnt(c->n_chunks, 0);
@@ -1676,6 +1692,7 @@ int launch_td_step(g2048_ctx* c, float alpha, hipEvent_t ev = nullptr) {
                                                              c->auto_reset, c->stats, c->last_move, c->log)));
     if (ev) (void)hipEventRecord(ev, c->stream);
     if (c->update_mode == 1) {
+        if (const char* e = getenv("G2048_REPLAN_EVERY")) c->replan_every = (uint32_t)atoi(e);       // (experiments)
         if (c->steps_since_plan >= c->replan_every)
             if (int rc = replan(c)) return rc;
         ++c->steps_since_plan;
@@ -1782,9 +1799,11 @@ int g2048_destroy(g2048_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* bufs[] = {c->log.moves, c->log.start, c->log.meta, c->boards, c->scores, c->rng, c->prev[0], c->prev[1], c->oidx[0], c->oidx[1], c->label, c->flags, c->dw1, c->qstate,
-                    c->qdw,    c->qcount, c->last_move, c->w,      c->w0,  c->delta,   c->stats,   c->scratch, c->slices, c->hits, c->D, c->Dcnt, c->D2, c->Dcnt2, c->wg_clock};
+                    c->qdw,    c->qcount, c->last_move, c->w,      c->w0,  c->delta,   c->stats,   c->scratch, c->slices, c->statbuf, c->D, c->Dcnt, c->D2, c->Dcnt2};
     for (void* p : bufs)
         if (p && (p != (void*)c->w || c->owns_table)) (void)hipFree(p);
+    if (c->h_stat) (void)hipHostFree(c->h_stat);
+    if (c->h_slices) (void)hipHostFree(c->h_slices);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
