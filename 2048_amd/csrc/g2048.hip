@@ -302,6 +302,11 @@ __global__ __launch_bounds__(WG) void k_features(const uint4* boards, uint32_t B
 }
 
 // QAgent.evaluate (r_learning.py:202-203): left-to-right sum of one weight per feature (fp32 here, float64 there)
+// One table entry.  (Forcing the scalar-base + 32-bit-vector-offset form of global_load — an opaque 32-bit byte offset,
+// so that a pending gather holds one address register instead of a 64-bit pair — was measured: same register count after
+// allocation, k_td_play 0.200 -> 0.210 ms.  Plain indexing it is.)
+__device__ __forceinline__ float ld_w(const float* __restrict__ w, uint32_t slot) { return w[slot]; }
+
 template <int N>
 __device__ __forceinline__ float value_of(const float* __restrict__ w, const Board& b) {
     constexpr int F = Shape<N>::F;
@@ -309,7 +314,7 @@ __device__ __forceinline__ float value_of(const float* __restrict__ w, const Boa
     feature_slots<N>(pack_board(b), s);
     float x[F];
 #pragma unroll
-    for (int f = 0; f < F; ++f) x[f] = w[s[f]];
+    for (int f = 0; f < F; ++f) x[f] = ld_w(w, s[f]);
     float v = 0.0f;
 #pragma unroll
     for (int f = 0; f < F; ++f) v += x[f];
@@ -322,6 +327,14 @@ __global__ __launch_bounds__(WG) void k_evaluate(const uint4* boards, uint32_t B
     if (i >= B) return;
     value[i] = value_of<N>(w, ld_board(boards, i));
 }
+
+// how many candidate directions have their table gathers in flight together (register pressure against latency hiding)
+#ifndef G2048_BATCH4_MAXF
+#define G2048_BATCH4_MAXF 24
+#endif
+#ifndef G2048_BATCH2_MAXF
+#define G2048_BATCH2_MAXF 40
+#endif
 
 struct Choice {
     int action;         // -1: no direction changes the board
@@ -341,7 +354,7 @@ __device__ __forceinline__ Choice choose(const float* __restrict__ w, const Move
     c.action = -1;
     c.value = -INFINITY;
     int first_valid = -1;
-    if constexpr (F <= 24) {
+    if constexpr (F <= G2048_BATCH4_MAXF) {
         uint32_t s0[F], s1[F], s2[F], s3[F];
         feature_slots<N>(pack_board(mv.m0.after), s0);
         feature_slots<N>(pack_board(mv.m1.after), s1);
@@ -350,10 +363,10 @@ __device__ __forceinline__ Choice choose(const float* __restrict__ w, const Move
         float x0[F], x1[F], x2[F], x3[F];
 #pragma unroll
         for (int f = 0; f < F; ++f) {
-            x0[f] = w[mv.m0.changed ? s0[f] : 0u];
-            x1[f] = w[mv.m1.changed ? s1[f] : 0u];
-            x2[f] = w[mv.m2.changed ? s2[f] : 0u];
-            x3[f] = w[mv.m3.changed ? s3[f] : 0u];
+            x0[f] = ld_w(w, mv.m0.changed ? s0[f] : 0u);
+            x1[f] = ld_w(w, mv.m1.changed ? s1[f] : 0u);
+            x2[f] = ld_w(w, mv.m2.changed ? s2[f] : 0u);
+            x3[f] = ld_w(w, mv.m3.changed ? s3[f] : 0u);
         }
         float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f, v3 = 0.0f;      // each a left-to-right sum, as QAgent.evaluate
 #pragma unroll
@@ -377,7 +390,7 @@ __device__ __forceinline__ Choice choose(const float* __restrict__ w, const Move
                     c.action = d;
                 }
             }
-    } else if constexpr (F <= 40) {
+    } else if constexpr (F <= G2048_BATCH2_MAXF) {
         // two directions per round (2 F loads in flight per lane)
 #define G2048_TRY_PAIR(DA, MA, DB, MB)                                               \
     {                                                                                \
@@ -386,8 +399,8 @@ __device__ __forceinline__ Choice choose(const float* __restrict__ w, const Move
         feature_slots<N>(pack_board((MB).after), sb);                                \
         float xa[F], xb[F];                                                          \
         _Pragma("unroll") for (int f = 0; f < F; ++f) {                              \
-            xa[f] = w[(MA).changed ? sa[f] : 0u];                                    \
-            xb[f] = w[(MB).changed ? sb[f] : 0u];                                    \
+            xa[f] = ld_w(w, (MA).changed ? sa[f] : 0u);                              \
+            xb[f] = ld_w(w, (MB).changed ? sb[f] : 0u);                              \
         }                                                                            \
         float va = 0.0f, vb = 0.0f;                                                  \
         _Pragma("unroll") for (int f = 0; f < F; ++f) {                              \
@@ -607,11 +620,14 @@ __global__ __launch_bounds__(WG) void k_td_play(uint4* boards, int32_t* scores, 
     constexpr float F = (float)Shape<N>::F;
     __shared__ WgStats ws;
     wg_stats_init(&ws);
-    uint32_t i = blockIdx.x * WG + threadIdx.x;
-    if (i == 0) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
         *recs.qcount_next = 0;
         *recs.dwmax_next = 0;
     }
+    // A workgroup walks over lane blocks (grid-stride); play_grid decides whether the grid is the whole batch (one
+    // iteration) or what the chip holds at once.  The trip count is uniform within a workgroup.
+    for (uint32_t base = blockIdx.x * WG; base < B; base += gridDim.x * WG) {
+    const uint32_t i = base + threadIdx.x;
     bool moved = false;
     float dw_big = 0.0f;            // largest |dw| this lane emits
     if (i < B) {
@@ -692,6 +708,7 @@ __global__ __launch_bounds__(WG) void k_td_play(uint4* boards, int32_t* scores, 
     }
     if (dw_big > 0.0f && isfinite(dw_big)) atomicMax(&ws.dw_max_bits, __float_as_uint(dw_big));
     count_moves(&ws, moved ? 1u : 0u);
+    }
     wg_stats_flush(&ws, stats);
     if (threadIdx.x == 0 && ws.dw_max_bits) atomicMax(recs.dwmax, ws.dw_max_bits);
 }
@@ -1195,6 +1212,7 @@ struct g2048_ctx {
     uint32_t n_slices = 0;
     uint32_t* hits = nullptr;           // adds per table chunk since the last re-plan (load statistics)
     uint32_t n_chunks = 0;
+    unsigned play_wgs = 0;          // persistent grid of k_td_play (0 = not determined yet)
     uint32_t owned_total = 0;       // D[0 .. owned_total): the LDS-owned orbit tables (cleared by the host after k_apply_orbits)
     uint32_t steps_since_plan = 0, replan_every = 8;     // the board distribution drifts with the games' age: follow it closely
     std::vector<double> load;           // smoothed adds per step per chunk
@@ -1671,6 +1689,24 @@ int replan(g2048_ctx* c) {
     return build_slices(c);
 }
 
+// workgroups of k_td_play: as many as are resident at once (occupancy x CUs), or fewer if the batch is small
+template <int N>
+unsigned play_grid(g2048_ctx* c) {
+    if (!c->play_wgs) {
+        int per_cu = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_td_play<N>, WG, 0) != hipSuccess || per_cu <= 0) per_cu = 2;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || cus <= 0) cus = 256;
+        c->play_wgs = (unsigned)(per_cu * cus);
+        if (const char* e = getenv("G2048_PLAY_WGS")) c->play_wgs = (unsigned)atoi(e);       // (experiments)
+    }
+    // persistent only when the lane blocks divide evenly over the resident workgroups (2^20 lanes: n = 4 holds 1 024
+    // workgroups -> 4 blocks each, k_td_play 0.176 -> 0.145 ms; n = 5 holds 768 -> 5.33, where the hardware's own
+    // dispatch of 4 096 workgroups balances better than 5-or-6 iterations do: 0.189 against 0.200 ms)
+    const unsigned need = grid_for(c->B);
+    if (need <= c->play_wgs || need % c->play_wgs != 0) return need;
+    return c->play_wgs;
+}
+
 // One TD step on the context's stream: k_td_play, then the update in the selected mode.  `ev` (optional) gets an
 // event between the two parts.
 int launch_td_step(g2048_ctx* c, float alpha, hipEvent_t ev = nullptr) {
@@ -1688,7 +1724,7 @@ int launch_td_step(g2048_ctx* c, float alpha, hipEvent_t ev = nullptr) {
     recs.unit = 0;
     recs.oidx = c->oidx[c->cur];
     recs.oidx_nxt = c->oidx[c->cur ^ 1];
-    BY_N(c, (k_td_play<N><<<grid_for(B), WG, 0, c->stream>>>(c->boards, c->scores, c->rng, pn, c->label, c->flags, B, c->w, alpha, recs,
+    BY_N(c, (k_td_play<N><<<play_grid<N>(c), WG, 0, c->stream>>>(c->boards, c->scores, c->rng, pn, c->label, c->flags, B, c->w, alpha, recs,
                                                              c->auto_reset, c->stats, c->last_move, c->log)));
     if (ev) (void)hipEventRecord(ev, c->stream);
     if (c->update_mode == 1) {

@@ -115,6 +115,15 @@ def side_workload(pkg, args):
     eng.close()
 
 
+def gather_floor_ms(n, B, device):
+    """Time for the table gathers of one k_td_play launch at one lane per cycle per CU (the measured rate of divergent
+    4-byte loads through the texture addresser)."""
+    import torch
+    p = torch.cuda.get_device_properties(device)
+    clock_hz = getattr(p, 'clock_rate', 2400000) * 1e3
+    return 4.0 * NUM_FEAT[n] * B / (p.multi_processor_count * clock_hz) * 1e3
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -242,6 +251,9 @@ def main():
                          'algorithmic_bytes_per_launch': dom_bytes, 'ms_per_launch': dom_ms,
                          'ms_k_td_play': ms_play, 'ms_k_td_update': ms_update,
                          'whole_step_algorithmic_GBps': (by_play + by_update) * B / (dt / K) / 1e9,
+                         # k_td_play's own bound is not HBM: 4 x num_feat divergent 4-byte gathers per lane pass the CU's address
+                         # unit at ~1 lane per cycle; this is that floor for one launch
+                         'ms_k_td_play_gather_floor': gather_floor_ms(n, B, local_rank),
                          'measured_copy_GBps': copy_gbps},
             'hip_event_ms_per_step': ev_ms / K,
             'episodes_finished': st['episodes'],
