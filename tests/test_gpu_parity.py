@@ -470,6 +470,25 @@ def test_shared_table_contexts_and_last_move():
 
 # ------------------------------------------------------------------ error behaviour
 
+def test_owner_plan_diagnostics_cover_every_chunk_once():
+    """g2048_debug_owner_plan: the LDS-owner plan in use and the clocks of its last launch.  The parts of every chunk
+    must tile the records exactly once, and every workgroup must have run (end clock after start clock)."""
+    n, B = 5, 1 << 17
+    eng = Engine(B, n=n, seed=12)
+    eng.init_weights(seed=3, scale=0.01)
+    eng.td_steps(0.25 * 21 / (8.0 * B), 20)                                  # two replans with measured costs
+    eng.sync()
+    plan = eng.debug_owner_plan().astype(np.int64)
+    assert len(plan) > 0 and len(plan) <= 1024
+    assert (plan[:, 5] > plan[:, 4]).all()
+    for chunk in np.unique(plan[:, 1]):
+        rows = plan[plan[:, 1] == chunk]
+        nparts = rows[0, 3]
+        assert (rows[:, 3] == nparts).all() and len(np.unique(rows[:, 0])) == 1
+        assert sorted(rows[:, 2].tolist()) == list(range(nparts))
+    eng.close()
+
+
 def test_error_codes():
     from ctypes import byref, c_void_p
     lib = pkg.load_library()
