@@ -493,6 +493,9 @@ constexpr int ORBIT_REPS[6] = {0, 1, 8, 9, 12, 17};
 // is fixed by the whole group).  4 + 4 + 4 + 4 + 1 + 4 = 21 LDS adds per record instead of 48.  find_orbits verifies
 // these masks against the brute-force enumeration of all 8 images.
 constexpr uint32_t COSET_MASK[6] = {0x27u, 0x27u, 0x55u, 0x1Bu, 0x01u, 0x55u};
+// the two f_6 orbits (k_td_update_tail): the corner blocks' representative (feature 21) is fixed by nothing, the middle
+// blocks' (feature 22) by the left-right mirror
+constexpr uint32_t HEX_COSET_MASK[2] = {0xFFu, 0x1Bu};
 #ifndef G2048_FIXED_VARIANTS
 #define G2048_FIXED_VARIANTS 5      // (6 = the cross orbit too: twice the chunks to scan, measured 0.20 -> 0.245 ms)
 #endif
@@ -1037,9 +1040,18 @@ __global__ __launch_bounds__(WG) void k_apply_orbits(float* w, float* D, const f
     const OrbitInfo& oi = t.o[o];
     const uint32_t k = K - oi.base;
     float v;
+    uint32_t k2 = k;        // f_6 orbit with a stabiliser {e, sigma}: the thread of the smaller of k, sigma(k) serves both
     if (K >= owned) {
         v = D[K];
-        if (v == 0.0f) return;
+        if (oi.nstab == 2) {
+            k2 = permute_digits(k, oi.sperm[1], oi.digits, oi.radix);
+            if (k2 < k) return;
+            v += D[oi.base + k2];
+            if (v == 0.0f) return;
+            D[oi.base + k2] = 0.0f;
+        } else if (v == 0.0f) {
+            return;
+        }
         D[K] = 0.0f;
     } else {            // symmetrise over the stabiliser
         v = cur[K];
@@ -1047,6 +1059,8 @@ __global__ __launch_bounds__(WG) void k_apply_orbits(float* w, float* D, const f
         if (v == 0.0f) return;
     }
     for (uint32_t m = 0; m < oi.nmem; ++m) w[oi.off[m] + permute_digits(k, oi.perm[m], oi.digits, oi.radix)] += v;
+    if (k2 != k)
+        for (uint32_t m = 0; m < oi.nmem; ++m) w[oi.off[m] + permute_digits(k2, oi.perm[m], oi.digits, oi.radix)] += v;
 }
 
 // Per-slot mean rule (g2048_set_update_rule): S = sum of the dw that target a slot, C = how many did; the slot moves
@@ -1066,10 +1080,21 @@ __global__ __launch_bounds__(WG) void k_apply_orbits_mean(float* w, float* S, fl
     const OrbitInfo& oi = t.o[o];
     const uint32_t k = K - oi.base;
     float cnt, sum;
+    uint32_t k2 = k;
     if (K >= owned) {
         cnt = C[K];
         sum = S[K];
-        if (cnt == 0.0f) return;
+        if (oi.nstab == 2) {
+            k2 = permute_digits(k, oi.sperm[1], oi.digits, oi.radix);
+            if (k2 < k) return;
+            cnt += C[oi.base + k2];
+            sum += S[oi.base + k2];
+            if (cnt == 0.0f) return;
+            S[oi.base + k2] = 0.0f;
+            C[oi.base + k2] = 0.0f;
+        } else if (cnt == 0.0f) {
+            return;
+        }
         S[K] = 0.0f;
         C[K] = 0.0f;
     } else {
@@ -1084,6 +1109,8 @@ __global__ __launch_bounds__(WG) void k_apply_orbits_mean(float* w, float* S, fl
     }
     const float v = sum / cnt;
     for (uint32_t m = 0; m < oi.nmem; ++m) w[oi.off[m] + permute_digits(k, oi.perm[m], oi.digits, oi.radix)] += v;
+    if (k2 != k)
+        for (uint32_t m = 0; m < oi.nmem; ++m) w[oi.off[m] + permute_digits(k2, oi.perm[m], oi.digits, oi.radix)] += v;
 }
 
 __global__ __launch_bounds__(WG) void k_apply_flat_mean(float* w, float* S, float* C, uint32_t slots) {
@@ -1140,7 +1167,7 @@ __global__ __launch_bounds__(OWN_WG) void k_td_update_tail(float* D, TdRecs recs
         uint32_t s[F];
         feature_slots<N>(d4_image(p, g), s);
         cached_add(keys, vals, D, dbaseA + (s[21] - feature_offset(N, 21)), dw);
-        cached_add(keys, vals, D, dbaseB + (s[22] - feature_offset(N, 22)), dw);
+        if ((HEX_COSET_MASK[1] >> g) & 1u) cached_add(keys, vals, D, dbaseB + (s[22] - feature_offset(N, 22)), dw);     // one image per coset
     }
     __syncthreads();
     for (uint32_t j = threadIdx.x; j < TAIL_CACHE; j += OWN_WG)
@@ -1402,20 +1429,26 @@ int find_orbits(g2048_ctx* c) {
             rep_of.push_back(i);
         }
     }
-    // stabiliser of every LDS-owned representative, and the check of the owner kernel's coset masks
+    // stabiliser of every representative, and the check of the kernels' coset masks
     for (uint32_t o = 0; o < T.count; ++o) {
         OrbitInfo& oi = T.o[o];
         oi.nstab = 1;
         oi.sperm[0] = oi.perm[0];                                   // identity
-        if (oi.radix != 16u) continue;
-        if (o >= 6 || rep_of[o] != ORBIT_REPS[o]) return fail(c, G2048_ERR_STATE, "unexpected orbit structure");
-        c->owned_total = oi.base + oi.size;
-        const uint32_t nd = oi.digits;
+        uint32_t mask;
+        if (oi.radix == 16u) {
+            if (o >= 6 || rep_of[o] != ORBIT_REPS[o]) return fail(c, G2048_ERR_STATE, "unexpected orbit structure");
+            c->owned_total = oi.base + oi.size;
+            mask = COSET_MASK[o];
+        } else {
+            if (o < 6 || o >= 8) return fail(c, G2048_ERR_STATE, "unexpected f_6 orbit structure");
+            mask = HEX_COSET_MASK[o - 6];
+        }
+        const uint32_t nd = oi.digits, radix = oi.radix;
         uint32_t mine[NB][6];
-        for (int t = 0; t < NB; ++t) digits_of(host_feature_index<N>(boards[t], rep_of[o]), 16u, nd, mine[t]);
+        for (int t = 0; t < NB; ++t) digits_of(host_feature_index<N>(boards[t], rep_of[o]), radix, nd, mine[t]);
         for (uint32_t g = 1; g < 8; ++g) {
             uint32_t theirs[NB][6];
-            for (int t = 0; t < NB; ++t) digits_of(host_feature_index<N>(d4_image(boards[t], g), rep_of[o]), 16u, nd, theirs[t]);
+            for (int t = 0; t < NB; ++t) digits_of(host_feature_index<N>(d4_image(boards[t], g), rep_of[o]), radix, nd, theirs[t]);
             uint32_t perm = 0, used = 0;
             bool ok = true;
             for (uint32_t pp = 0; pp < nd && ok; ++pp) {
@@ -1435,13 +1468,14 @@ int find_orbits(g2048_ctx* c) {
             }
             if (ok) oi.sperm[oi.nstab++] = perm;
         }
+        if (radix != 16u && oi.nstab > 2) return fail(c, G2048_ERR_STATE, "unexpected f_6 stabiliser");      // k_apply_orbits pairs k with sigma(k)
         for (int t = 0; t < NB; ++t) {
             std::vector<uint32_t> all, folded;
             for (uint32_t g = 0; g < 8; ++g) {
                 const uint32_t idx = host_feature_index<N>(d4_image(boards[t], g), rep_of[o]);
                 all.push_back(idx);
-                if ((COSET_MASK[o] >> g) & 1u)
-                    for (uint32_t st = 0; st < oi.nstab; ++st) folded.push_back(permute_digits(idx, oi.sperm[st], nd, 16u));
+                if ((mask >> g) & 1u)
+                    for (uint32_t st = 0; st < oi.nstab; ++st) folded.push_back(permute_digits(idx, oi.sperm[st], nd, radix));
             }
             std::sort(all.begin(), all.end());
             std::sort(folded.begin(), folded.end());
