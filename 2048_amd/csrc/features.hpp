@@ -224,4 +224,23 @@ G2048_HD constexpr uint32_t feature_size(int n, int i) {
     }
 }
 
+// ---- symmetry orbits of the update (g2048.hip: LDS-owner kernels, k_td_play's index records, k_td_update_tail)
+// n >= 4: one variant per LDS-owned orbit, encoding the orbit's representative feature (outer line 0, inner line 1,
+// corner square 8, edge square 9, centre square 12, cross 17; find_orbits checks that these are the representatives)
+constexpr int ORBIT_REPS[6] = {0, 1, 8, 9, 12, 17};
+// images (bit g = d4_image g) that the owner kernel visits for each representative: one per coset of its stabiliser
+// (columns 0 / 1: up-down mirror; corner square and cross: transpose; edge square: left-right mirror; the centre square
+// is fixed by the whole group).  4 + 4 + 4 + 4 + 1 + 4 = 21 LDS adds per record instead of 48.  find_orbits verifies
+// these masks against the brute-force enumeration of all 8 images.
+constexpr uint32_t COSET_MASK[6] = {0x27u, 0x27u, 0x55u, 0x1Bu, 0x01u, 0x55u};
+// the two f_6 orbits (k_td_update_tail): the corner blocks' representative (feature 21) is fixed by nothing, the middle
+// blocks' (feature 22) by the left-right mirror
+constexpr uint32_t HEX_COSET_MASK[2] = {0xFFu, 0x1Bu};
+// the j-th visited image of orbit variant V
+constexpr uint32_t coset_rank(uint32_t mask, uint32_t g) {
+    uint32_t r = 0;
+    for (uint32_t b = 0; b < g; ++b) r += (mask >> b) & 1u;
+    return r;
+}
+
 }  // namespace g2048

@@ -484,28 +484,6 @@ __global__ __launch_bounds__(WG) void k_update_records(float* w, const uint4* st
 //                           (r_learning.py:240); dw1[i] == 0 means "no record" (first move of a game, finished lane);
 //   terminal records      : (this step's afterstate, -V(after) * alpha / F) for lanes whose game ended after the spawn
 //                           (r_learning.py:248) — rare, so they go to a compact queue (one atomic counter bump per wave).
-// variant v of table N covers features [f0(v), f0(v) + fc(v))
-// n >= 4: one variant per LDS-owned orbit, encoding the orbit's representative feature (outer line 0, inner line 1,
-// corner square 8, edge square 9, centre square 12, cross 17; find_orbits checks that these are the representatives)
-constexpr int ORBIT_REPS[6] = {0, 1, 8, 9, 12, 17};
-// images (bit g = d4_image g) that the owner kernel visits for each representative: one per coset of its stabiliser
-// (columns 0 / 1: up-down mirror; corner square and cross: transpose; edge square: left-right mirror; the centre square
-// is fixed by the whole group).  4 + 4 + 4 + 4 + 1 + 4 = 21 LDS adds per record instead of 48.  find_orbits verifies
-// these masks against the brute-force enumeration of all 8 images.
-constexpr uint32_t COSET_MASK[6] = {0x27u, 0x27u, 0x55u, 0x1Bu, 0x01u, 0x55u};
-// the two f_6 orbits (k_td_update_tail): the corner blocks' representative (feature 21) is fixed by nothing, the middle
-// blocks' (feature 22) by the left-right mirror
-constexpr uint32_t HEX_COSET_MASK[2] = {0xFFu, 0x1Bu};
-#ifndef G2048_FIXED_VARIANTS
-#define G2048_FIXED_VARIANTS 5      // (6 = the cross orbit too: twice the chunks to scan, measured 0.20 -> 0.245 ms)
-#endif
-
-// the j-th visited image of orbit variant V
-constexpr uint32_t coset_rank(uint32_t mask, uint32_t g) {
-    uint32_t r = 0;
-    for (uint32_t b = 0; b < g; ++b) r += (mask >> b) & 1u;
-    return r;
-}
 
 struct TdRecs {
     const uint4* state1;    // prev[cur]
@@ -807,6 +785,9 @@ template <int N> struct OwnVariants { static constexpr int COUNT = N == 4 ? 5 : 
 template <> struct OwnVariants<2> { static constexpr int COUNT = 1; static constexpr int f0(int) { return 0; } static constexpr int fc(int) { return 24; } };
 template <> struct OwnVariants<3> { static constexpr int COUNT = 13; static constexpr int f0(int v) { return 4 * v; } static constexpr int fc(int) { return 4; } };   // 4 x 4096 fixed-point slots = 128 KiB
 
+#ifndef G2048_FIXED_VARIANTS
+#define G2048_FIXED_VARIANTS 5      // (6 = the cross orbit too: twice the chunks to scan, measured 0.20 -> 0.245 ms)
+#endif
 // which variants sum in 64-bit fixed point: the five four-cell orbits of n >= 4, and every feature group of n = 2, 3
 // (n = 3: 2.25 -> 0.36 ms per update, n = 2: 1.07 -> 0.24 ms)
 constexpr bool own_fixed(int n, int variant) { return n < 4 || variant < G2048_FIXED_VARIANTS; }

@@ -73,6 +73,16 @@ void hc_new_games(uint64_t seed, uint64_t lane0, int64_t count, uint8_t* boards)
     }
 }
 
+// the orbit representatives and coset masks the update kernels use: reps[8] (6 LDS-owned + the two f_6), masks[8]
+void hc_coset_masks(int32_t* reps, uint32_t* masks) {
+    for (int v = 0; v < 6; ++v) {
+        reps[v] = ORBIT_REPS[v];
+        masks[v] = COSET_MASK[v];
+    }
+    reps[6] = 21; reps[7] = 22;
+    masks[6] = HEX_COSET_MASK[0]; masks[7] = HEX_COSET_MASK[1];
+}
+
 // out[count][8][F] flat slots of every feature of every D4 image
 int hc_image_slots(int n, const uint8_t* boards, int64_t count, int32_t* out) {
     for (int64_t i = 0; i < count; ++i) {

@@ -122,6 +122,45 @@ def test_feature_slots_of_all_images(hc, golden, n):
         assert np.array_equal(out[:, gi, :], rb.slots(n, img))
 
 
+def test_coset_masks_reproduce_the_eight_images(hc):
+    """QAgent.update adds dw at f(g.x) for all 8 images g (r_learning.py:207-214).  The update kernels visit, for the
+    representative feature of each symmetry orbit, only the images of COSET_MASK and let the digit permutations of the
+    representative's stabiliser supply the rest: as a multiset, {sigma_t(f(g.x)) : g in mask, t in stabiliser} must equal
+    {f(g.x) : all 8 g}.  The stabiliser is found here by brute force, as find_orbits does on the device side."""
+    reps = np.zeros(8, np.int32)
+    masks = np.zeros(8, np.uint32)
+    hc.hc_coset_masks(ptr(reps), ptr(masks))
+    rng = np.random.default_rng(5)
+    boards = rng.integers(0, 14, size=(64, 16)).astype(np.uint8)            # f_6 clamps tiles at 13
+    n, F = 6, 33
+    out = np.zeros((len(boards), 8, F), np.int32)
+    assert hc.hc_image_slots(n, ptr(boards), ctypes.c_int64(len(boards)), ptr(out)) == 0
+    from oracle import ref_scalar as rs
+    offs, _ = rs.feature_offsets(n)
+    adds = 0
+    for rep, mask in zip(reps, masks):
+        radix, nd = (16, 4) if rep < 17 else (16, 5) if rep < 21 else (14, 6)
+        idx = out[:, :, rep] - offs[rep]                                     # [B, 8]
+        digits = np.stack([(idx // radix ** p) % radix for p in range(nd)], axis=-1)      # [B, 8, nd]
+        stab = []
+        for g in range(8):                                                   # f(x) = perm(f(g.x)) on every board?
+            perm, used = [], set()
+            for p in range(nd):
+                q = next((q for q in range(nd) if q not in used and np.array_equal(digits[:, 0, p], digits[:, g, q])), None)
+                if q is None:
+                    break
+                perm.append(q)
+                used.add(q)
+            if len(perm) == nd:
+                stab.append(perm)
+        images = [g for g in range(8) if (mask >> g) & 1]
+        assert len(stab) * len(images) == 8, (rep, stab, images)
+        folded = np.stack([sum(digits[:, g, perm[p]] * radix ** p for p in range(nd)) for g in images for perm in stab], axis=1)
+        assert np.array_equal(np.sort(folded, axis=1), np.sort(idx, axis=1)), rep
+        adds += len(images)
+    assert adds == 4 + 4 + 4 + 4 + 1 + 4 + 8 + 4
+
+
 def test_rng_stream_and_new_games(hc):
     seed, lane0, count, nd = 2048, 1000, 64, 16
     draws = np.zeros((count, nd), np.uint64)
