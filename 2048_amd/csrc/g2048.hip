@@ -1194,7 +1194,8 @@ struct g2048_ctx {
     int auto_reset = 1;
     int cur = 0;                        // which half of `prev` holds the current `state`
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_plan = nullptr;
+    bool plan_pending = false;          // replan_readback queued, replan not yet done
     uint4* boards = nullptr;
     int32_t* scores = nullptr;
     ulonglong2* rng = nullptr;
@@ -1669,12 +1670,23 @@ int build_slices(g2048_ctx* c) {
     return G2048_OK;
 }
 
-// read the hit counters, fold them into the smoothed load and rebuild the plan (a few tens of microseconds)
-int replan(g2048_ctx* c) {
+// Replan, first half (BEFORE the step's k_td_play is launched): one copy into pinned memory brings the hit counters and
+// the workgroup clocks of the steps so far.
+int replan_readback(g2048_ctx* c) {
     if (c->n < 4 || c->n_chunks == 0 || c->steps_since_plan == 0) return G2048_OK;
-    // one copy into pinned memory brings the hit counters and the workgroup clocks; the only wait of the replan
     HIP_TRY(c, hipMemcpyAsync(c->h_stat, c->statbuf, STAT_BYTES, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipEventRecord(c->ev_plan, c->stream));
+    c->plan_pending = true;
+    return G2048_OK;
+}
+
+// Second half (AFTER k_td_play is launched, before the update's launch): wait for that copy — the GPU is busy with
+// k_td_play for ~0.2 ms meanwhile, so it does not idle while the host folds the counters into the smoothed load,
+// rebuilds the plan (tens of microseconds) and queues its upload.
+int replan(g2048_ctx* c) {
+    if (!c->plan_pending) return G2048_OK;
+    c->plan_pending = false;
+    HIP_TRY(c, hipEventSynchronize(c->ev_plan));
     const uint32_t* h = reinterpret_cast<const uint32_t*>(c->h_stat);
     for (size_t k = 0; k < c->n_chunks; ++k) {
         const uint32_t fresh = h[k] - c->hits_seen[k];          // cumulative counters, modulo 2^32
@@ -1742,13 +1754,16 @@ int launch_td_step(g2048_ctx* c, float alpha, hipEvent_t ev = nullptr) {
     recs.unit = 0;
     recs.oidx = c->oidx[c->cur];
     recs.oidx_nxt = c->oidx[c->cur ^ 1];
+    if (c->update_mode == 1) {
+        if (const char* e = getenv("G2048_REPLAN_EVERY")) c->replan_every = (uint32_t)atoi(e);       // (experiments)
+        if (c->steps_since_plan >= c->replan_every)
+            if (int rc = replan_readback(c)) return rc;
+    }
     BY_N(c, (k_td_play<N><<<play_grid<N>(c), WG, 0, c->stream>>>(c->boards, c->scores, c->rng, pn, c->label, c->flags, B, c->w, alpha, recs,
                                                              c->auto_reset, c->stats, c->last_move, c->log)));
     if (ev) (void)hipEventRecord(ev, c->stream);
     if (c->update_mode == 1) {
-        if (const char* e = getenv("G2048_REPLAN_EVERY")) c->replan_every = (uint32_t)atoi(e);       // (experiments)
-        if (c->steps_since_plan >= c->replan_every)
-            if (int rc = replan(c)) return rc;
+        if (int rc = replan(c)) return rc;
         ++c->steps_since_plan;
         const uint32_t tail_grid = B >= (1u << 16) ? 512 : 16;
         recs.unit = 0;
@@ -1859,6 +1874,7 @@ int g2048_destroy(g2048_ctx* c) {
     if (c->h_stat) (void)hipHostFree(c->h_stat);
     if (c->h_slices) (void)hipHostFree(c->h_slices);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev_plan) (void)hipEventDestroy(c->ev_plan);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1894,7 +1910,9 @@ static int create_impl(int device, uint32_t batch, int n_tuple, uint64_t seed, u
     };
     if (hipSetDevice(device) != hipSuccess) return bail(G2048_ERR_HIP);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail(G2048_ERR_HIP);
-    if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) return bail(G2048_ERR_HIP);
+    if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_plan, hipEventDisableTiming) != hipSuccess)
+        return bail(G2048_ERR_HIP);
     const size_t B = batch;
     if ((rc = dalloc(c, &c->boards, B)) || (rc = dalloc(c, &c->scores, B)) || (rc = dalloc(c, &c->rng, B)) ||
         (rc = dalloc(c, &c->prev[0], B)) || (rc = dalloc(c, &c->prev[1], B)) || (rc = dalloc(c, &c->label, B)) ||
