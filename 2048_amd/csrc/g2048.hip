@@ -712,7 +712,7 @@ __global__ __launch_bounds__(WG) void k_td_update(float* w, TdRecs recs, uint32_
 // Random fp32 atomics to HBM-side memory run at ~21 G adds/s on MI355X and collapse under the skew of real boards
 // (a few hot slots: 7.8 G/s measured, tools/atomic_bench.hip); k_td_update spends 22 ms per step of 2^20 lanes on
 // them.  The chip has 256 x 160 KiB = 40 MiB of LDS, more than the whole n <= 5 table (21 MB): so instead a
-// workgroup OWNS a 128 KiB slice of the table in LDS, streams the step's (state, dw) records (20 B each, L2/MALL
+// workgroup OWNS a 128 KiB slice of the table in LDS, streams the step's records (n >= 4: its orbit's precomputed indices + dw, 12 B; else packed state + dw, 20 B; L2/MALL
 // resident), computes for each record and each of the 8 images only the slots of ITS feature(s), accumulates the
 // hits with LDS atomics, and finally adds the slice to the table in HBM with coalesced accesses.  With one
 // workgroup per slice the flush is a plain read-modify-write (no global atomics at all); when the records are split
@@ -808,7 +808,7 @@ __device__ __forceinline__ long long to_fixed(float dw, double scale) {
     return __double_as_longlong(fma((double)dw, scale, MAGIC)) - __double_as_longlong(MAGIC);
 }
 
-// FIXED: the four-cell orbits (n >= 4) take 40 of a record's 48 adds, and `ds_add_f32` manages 0.33 lane-adds per
+// FIXED: the four-cell orbits (n >= 4) take 17 of a record's 21 adds (40 of 48 before the coset reduction), and `ds_add_f32` manages 0.33 lane-adds per
 // cycle per CU against 4.1 for `ds_add_u64` (profiles/r01_lds_atomic_microbench.txt).  Their workgroups therefore sum
 // in 64-bit fixed point: dw * 2^S with S chosen from the step's largest |dw| so that 2^24 adds cannot overflow and a
 // dw 2^-14 times smaller than the largest is still exact; the flush converts back.  Half as many slots fit in LDS
