@@ -317,6 +317,33 @@ def test_td_mean_rule_vs_oracle(n):
     eng.close()
 
 
+@pytest.mark.parametrize('n', [3, 5, 6])
+def test_td_rule_and_mode_switches_mid_run(n):
+    """Switching between the sum and the mean rule, and between the two update kernels, between steps: the orbit tables
+    are double-buffered and the count buffers are only maintained under the mean rule, so every switch must start from
+    clean accumulators (odd numbers of steps in between flip the buffer parity)."""
+    B = 4096
+    eng = Engine(B, n=n, seed=400 + n)
+    eng.set_auto_reset(False)
+    eng.step_random(30)
+    k = 0
+
+    def steps(count, rule):
+        nonlocal k
+        for _ in range(count):
+            helpers.check_td_step(eng, n, formulas.exact_alpha(n), formulas.weights(n, scale=2.0 ** -(4 + k % 5)), rule=rule)
+            k += 1
+
+    eng.set_update_rule(1); steps(3, 'mean')
+    eng.set_update_rule(0); steps(3, 'sum')
+    eng.set_update_rule(1); steps(2, 'mean')
+    eng.set_update_rule(0); steps(1, 'sum')
+    eng.set_update_mode(0); steps(2, 'sum')                                  # global-atomics kernel
+    eng.set_update_mode(1); steps(2, 'sum')
+    eng.set_update_rule(1); steps(1, 'mean')
+    eng.close()
+
+
 @pytest.mark.parametrize('mode', [1, 0])
 def test_td_batch_until_all_games_end(mode):
     """256 lanes played to the end with learning on: the per-step check holds through terminal updates and DONE."""
