@@ -317,6 +317,20 @@ def test_td_mean_rule_vs_oracle(n):
     eng.close()
 
 
+def test_td_large_batch_vs_oracle_through_replans():
+    """131 072 lanes, n = 5: the size at which the XCD-resident plan and the measured-cost replans (every 8 steps) are
+    in use; every step is still checked against the float64 oracle."""
+    n, B = 5, 1 << 17
+    eng = Engine(B, n=n, seed=77)
+    eng.set_auto_reset(False)
+    eng.step_random(40)
+    for t in range(18):
+        helpers.check_td_step(eng, n, formulas.exact_alpha(n), formulas.weights(n, scale=2.0 ** -(4 + t % 4)))
+    plan = eng.debug_owner_plan()
+    assert len(plan) % 8 == 0                                                # parts come in multiples of the 8 XCDs
+    eng.close()
+
+
 @pytest.mark.parametrize('n', [3, 5, 6])
 def test_td_rule_and_mode_switches_mid_run(n):
     """Switching between the sum and the mean rule, and between the two update kernels, between steps: the orbit tables
