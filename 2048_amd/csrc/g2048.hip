@@ -492,6 +492,8 @@ struct TdRecs {
     float* qdw;             // [B]
     uint32_t* qcount;       // length of this step's queue
     uint32_t* qcount_next;  // next step's counter, zeroed by k_td_play
+    uint32_t* blocks;       // k_td_play's work counter: the next lane block to hand out
+    uint32_t* blocks_next;  // next step's, zeroed by k_td_play
     uint32_t unit;          // 1: every record counts as dw = 1 (the counting pass of the per-slot mean rule)
     uint32_t* dwmax;        // float bits of the largest |dw| among this step's records (scale of the fixed-point sums)
     uint32_t* dwmax_next;   // next step's, zeroed by k_td_play
@@ -604,10 +606,20 @@ __global__ __launch_bounds__(WG) void k_td_play(uint4* boards, int32_t* scores, 
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         *recs.qcount_next = 0;
         *recs.dwmax_next = 0;
+        *recs.blocks_next = 0;
     }
-    // A workgroup walks over lane blocks (grid-stride); play_grid decides whether the grid is the whole batch (one
-    // iteration) or what the chip holds at once.  The trip count is uniform within a workgroup.
-    for (uint32_t base = blockIdx.x * WG; base < B; base += gridDim.x * WG) {
+    // Persistent workgroups: the grid is what the chip holds at once (play_grid) and a workgroup takes lane blocks of 256
+    // from a counter until none is left — no workgroup launches and one statistics flush per workgroup instead of one
+    // per block, and the hardware's balance (a free slot takes the next block) is kept.  One atomic per block (4 096 per
+    // launch at 2^20 lanes; per-wave hand-out would be 16 384 on one address, which serialises at ~10 ns each).
+    __shared__ uint32_t next_block[2];
+    const uint32_t nblocks = (B + WG - 1) / WG;
+    for (uint32_t it = 0;; ++it) {
+    if (threadIdx.x == 0) next_block[it & 1u] = atomicAdd(recs.blocks, 1u);
+    __syncthreads();            // (the other slot is rewritten only after every thread has passed the next barrier)
+    const uint32_t blk = next_block[it & 1u];
+    if (blk >= nblocks) break;
+    const uint32_t base = blk * WG;
     const uint32_t i = base + threadIdx.x;
     bool moved = false;
     float dw_big = 0.0f;            // largest |dw| this lane emits
@@ -1212,7 +1224,7 @@ struct g2048_ctx {
     float* dw1 = nullptr;               // main record of every lane (0 = none)
     uint4* qstate = nullptr;            // terminal-record queue
     float* qdw = nullptr;
-    uint32_t* qcount = nullptr;         // [4]: this step's / next step's queue length, then this / next step's largest |dw| bits
+    uint32_t* qcount = nullptr;         // [6]: this / next step's queue length, largest |dw| bits, k_td_play block counter
     uint16_t* last_move = nullptr;      // what every lane did in the latest TD step (g2048_get_last_move)
     GameLog log = {0, 0, nullptr, nullptr, nullptr};
     uint32_t step_parity = 0;
@@ -1729,12 +1741,8 @@ unsigned play_grid(g2048_ctx* c) {
         c->play_wgs = (unsigned)(per_cu * cus);
         if (const char* e = getenv("G2048_PLAY_WGS")) c->play_wgs = (unsigned)atoi(e);       // (experiments)
     }
-    // persistent only when the lane blocks divide evenly over the resident workgroups (2^20 lanes: n = 4 holds 1 024
-    // workgroups -> 4 blocks each, k_td_play 0.176 -> 0.145 ms; n = 5 holds 768 -> 5.33, where the hardware's own
-    // dispatch of 4 096 workgroups balances better than 5-or-6 iterations do: 0.189 against 0.200 ms)
     const unsigned need = grid_for(c->B);
-    if (need <= c->play_wgs || need % c->play_wgs != 0) return need;
-    return c->play_wgs;
+    return need < c->play_wgs ? need : c->play_wgs;
 }
 
 // One TD step on the context's stream: k_td_play, then the update in the selected mode.  `ev` (optional) gets an
@@ -1751,6 +1759,8 @@ int launch_td_step(g2048_ctx* c, float alpha, hipEvent_t ev = nullptr) {
     recs.qcount_next = c->qcount + (c->step_parity ^ 1u);
     recs.dwmax = c->qcount + 2 + c->step_parity;
     recs.dwmax_next = c->qcount + 2 + (c->step_parity ^ 1u);
+    recs.blocks = c->qcount + 4 + c->step_parity;
+    recs.blocks_next = c->qcount + 4 + (c->step_parity ^ 1u);
     recs.unit = 0;
     recs.oidx = c->oidx[c->cur];
     recs.oidx_nxt = c->oidx[c->cur ^ 1];
@@ -1917,7 +1927,7 @@ static int create_impl(int device, uint32_t batch, int n_tuple, uint64_t seed, u
     if ((rc = dalloc(c, &c->boards, B)) || (rc = dalloc(c, &c->scores, B)) || (rc = dalloc(c, &c->rng, B)) ||
         (rc = dalloc(c, &c->prev[0], B)) || (rc = dalloc(c, &c->prev[1], B)) || (rc = dalloc(c, &c->label, B)) ||
         (rc = dalloc(c, &c->flags, B)) || (rc = dalloc(c, &c->dw1, B)) || (rc = dalloc(c, &c->qstate, B)) || (rc = dalloc(c, &c->qdw, B)) ||
-        (rc = dalloc(c, &c->qcount, 4)) || (rc = dalloc(c, &c->last_move, B)) ||
+        (rc = dalloc(c, &c->qcount, 8)) || (rc = dalloc(c, &c->last_move, B)) ||
         (rc = dalloc(c, &c->stats, 1)))
         return bail(rc);
     if (n_tuple >= 4 && ((rc = dalloc(c, &c->oidx[0], OIDX_BYTES_PER_LANE * B)) || (rc = dalloc(c, &c->oidx[1], OIDX_BYTES_PER_LANE * B)))) return bail(rc);
@@ -1931,7 +1941,7 @@ static int create_impl(int device, uint32_t batch, int n_tuple, uint64_t seed, u
     if (hipMemsetAsync(c->stats, 0, sizeof(Stats), c->stream) != hipSuccess ||
         hipMemsetAsync(c->prev[0], 0, B * sizeof(uint4), c->stream) != hipSuccess ||
         hipMemsetAsync(c->prev[1], 0, B * sizeof(uint4), c->stream) != hipSuccess ||
-        hipMemsetAsync(c->qcount, 0, 16, c->stream) != hipSuccess || hipMemsetAsync(c->last_move, 0, B * 2, c->stream) != hipSuccess || hipMemsetAsync(c->dw1, 0, B * 4, c->stream) != hipSuccess ||
+        hipMemsetAsync(c->qcount, 0, 32, c->stream) != hipSuccess || hipMemsetAsync(c->last_move, 0, B * 2, c->stream) != hipSuccess || hipMemsetAsync(c->dw1, 0, B * 4, c->stream) != hipSuccess ||
         (slots && !parent && hipMemsetAsync(c->w, 0, slots * sizeof(float), c->stream) != hipSuccess))
         return bail(G2048_ERR_HIP);
     k_seed<<<grid_for(B), WG, 0, c->stream>>>(c->rng, batch, seed, lane0);
