@@ -8,7 +8,7 @@ eng = pkg.Engine(B, n=n, seed=2048)
 eng.init_weights(seed=7, scale=0.01)
 alpha = 0.25 * eng.num_feat / (8.0 * B)
 done = 0
-for upto in (64, 264, 1000, 2500, 5000, 10000):
+for upto in [int(x) for x in os.environ.get("UPTO", "64,264,1000,2500,5000,10000").split(",")]:
     eng.td_steps(alpha, upto - done)
     done = upto
     a, b = eng.td_steps_profiled(alpha, 16)
