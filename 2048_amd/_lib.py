@@ -12,7 +12,8 @@ from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_uint8,
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'lib2048_hip.so')
 
-OK, ERR_ARG, ERR_HIP, ERR_NOMEM, ERR_STATE, ERR_NODEV = 0, -1, -2, -3, -4, -5
+OK, ERR_ARG, ERR_HIP, ERR_NOMEM, ERR_STATE, ERR_NODEV, ERR_COMM = 0, -1, -2, -3, -4, -5, -6
+COMM_ID_BYTES = 128
 LANE_HAS_PREV, LANE_DONE = 1, 2
 
 
@@ -24,7 +25,7 @@ class G2048Error(RuntimeError):
 
 class Stats(ctypes.Structure):
     _fields_ = [('episodes', c_uint64), ('moves', c_uint64), ('score_sum', c_uint64), ('best_score', c_uint64),
-                ('max_tile', c_uint64 * 20), ('overflow16', c_uint64)]
+                ('max_tile', c_uint64 * 20), ('overflow16', c_uint64), ('nonfinite', c_uint64), ('valid_dirs', c_uint64)]
 
 
 _P = c_void_p          # opaque context / generic buffers (numpy arrays are passed by address)
@@ -86,6 +87,14 @@ SIGNATURES = {
     'g2048_td_steps_profiled': (c_int, [_P, c_float, c_uint32, POINTER(c_float), POINTER(c_float)]),
     'g2048_debug_owner_plan': (c_int, [_P, _P, c_uint32, POINTER(c_uint32)]),
     'g2048_stream_handle': (c_int, [_P, POINTER(_P)]),
+    'g2048_td_steps_kernel_ms': (c_int, [_P, c_float, c_uint32, _P]),
+    'g2048_delta_pack_touched': (c_int, [_P, _P]),
+    'g2048_delta_apply_mean': (c_int, [_P, _P]),
+    'g2048_comm_unique_id': (c_int, [_P]),
+    'g2048_comm_init': (c_int, [_P, c_int, c_int, _P]),
+    'g2048_comm_destroy': (c_int, [_P]),
+    'g2048_allreduce_deltas': (c_int, [_P]),
+    'g2048_allreduce_f64': (c_int, [_P, _P, c_int, c_int]),
 }
 
 _lib = None
@@ -103,7 +112,7 @@ def load():
             fn = getattr(lib, name)          # AttributeError here = header and library disagree
             fn.restype = res
             fn.argtypes = args
-        if lib.g2048_abi_version() != 1:
+        if lib.g2048_abi_version() != 2:
             raise G2048Error(ERR_STATE, 'ABI version mismatch')
         _lib = lib
     return _lib

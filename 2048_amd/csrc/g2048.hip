@@ -14,6 +14,8 @@
 // There is no dense contraction anywhere on this path: no MFMA.  The kernels are integer SWAR + random 4-byte
 // gathers + fp32 atomic adds; what bounds them is the memory system, not the VALU.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>      // types only: the library is bound with dlopen (g2048_comm_init)
+#include <dlfcn.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -62,7 +64,7 @@ __device__ __forceinline__ void st_packed(uint4* p, size_t i, const Packed& q) {
 }
 
 struct Stats {   // device mirror of g2048_stats (all u64)
-    unsigned long long episodes, moves, score_sum, best_score, max_tile[20], overflow16;
+    unsigned long long episodes, moves, score_sum, best_score, max_tile[20], overflow16, nonfinite, valid_dirs;
 };
 static_assert(sizeof(Stats) == sizeof(g2048_stats), "stats layout");
 
@@ -71,7 +73,7 @@ static_assert(sizeof(Stats) == sizeof(g2048_stats), "stats layout");
 // atomics run at well under 1 G/s).
 struct WgStats {
     unsigned long long score_sum;
-    unsigned int episodes, moves, best, overflow16, max_tile[20];
+    unsigned int episodes, moves, valid_dirs, best, overflow16, nonfinite, max_tile[20];
     unsigned int dw_max_bits;       // largest |dw| of the workgroup's records, as float bits (orders like an unsigned int)
 };
 
@@ -79,7 +81,7 @@ __device__ __forceinline__ void wg_stats_init(WgStats* ws) {
     if (threadIdx.x < 20) ws->max_tile[threadIdx.x] = 0;
     if (threadIdx.x == 0) {
         ws->score_sum = 0;
-        ws->episodes = ws->moves = ws->best = ws->overflow16 = 0;
+        ws->episodes = ws->moves = ws->valid_dirs = ws->best = ws->overflow16 = ws->nonfinite = 0;
         ws->dw_max_bits = 0;
     }
     __syncthreads();
@@ -95,11 +97,17 @@ __device__ __forceinline__ void count_finished(WgStats* ws, const Board& b, int3
     if (overflow) atomicAdd(&ws->overflow16, 1u);
 }
 
-// board-steps executed: one LDS add per wave
-__device__ __forceinline__ void count_moves(WgStats* ws, unsigned int my_moves) {
+// board-steps executed and directions that were open to them: one LDS add per wave each
+__device__ __forceinline__ void count_moves(WgStats* ws, unsigned int my_moves, unsigned int my_dirs) {
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) my_moves += __shfl_down(my_moves, off);
-    if ((threadIdx.x & 63) == 0 && my_moves) atomicAdd(&ws->moves, my_moves);
+    for (int off = 32; off > 0; off >>= 1) {
+        my_moves += __shfl_down(my_moves, off);
+        my_dirs += __shfl_down(my_dirs, off);
+    }
+    if ((threadIdx.x & 63) == 0 && my_moves) {
+        atomicAdd(&ws->moves, my_moves);
+        atomicAdd(&ws->valid_dirs, my_dirs);
+    }
 }
 
 __device__ __forceinline__ void wg_stats_flush(const WgStats* ws, Stats* st) {
@@ -108,9 +116,11 @@ __device__ __forceinline__ void wg_stats_flush(const WgStats* ws, Stats* st) {
     if (threadIdx.x == 32) {
         if (ws->episodes) atomicAdd(&st->episodes, (unsigned long long)ws->episodes);
         if (ws->moves) atomicAdd(&st->moves, (unsigned long long)ws->moves);
+        if (ws->valid_dirs) atomicAdd(&st->valid_dirs, (unsigned long long)ws->valid_dirs);
         if (ws->score_sum) atomicAdd(&st->score_sum, ws->score_sum);
         if (ws->best) atomicMax(&st->best_score, (unsigned long long)ws->best);
         if (ws->overflow16) atomicAdd(&st->overflow16, (unsigned long long)ws->overflow16);
+        if (ws->nonfinite) atomicAdd(&st->nonfinite, (unsigned long long)ws->nonfinite);
     }
 }
 
@@ -250,7 +260,7 @@ __global__ __launch_bounds__(WG) void k_step_random(uint4* boards, int32_t* scor
         score = scores[i];
         fl = flags[i];
     }
-    uint32_t my_moves = 0;
+    uint32_t my_moves = 0, my_dirs = 0;
     for (uint32_t s = 0; s < nsteps; ++s) {
         if (fl & DONE) continue;
         Moves4 mv = all_moves(b);
@@ -263,6 +273,7 @@ __global__ __launch_bounds__(WG) void k_step_random(uint4* boards, int32_t* scor
             b = c.after;
             score += (int32_t)merged_score(c.ma, c.mb);
             ++my_moves;
+            my_dirs += popcount32(mask);
             spawn(b, g);
             over = game_over(b) || max_tile(b) >= 16u;
         } else {
@@ -278,7 +289,7 @@ __global__ __launch_bounds__(WG) void k_step_random(uint4* boards, int32_t* scor
             }
         }
     }
-    count_moves(&ws, my_moves);
+    count_moves(&ws, my_moves, my_dirs);
     wg_stats_flush(&ws, stats);
     if (in) {
         st_board(boards, i, b);
@@ -461,22 +472,28 @@ __global__ __launch_bounds__(WG) void k_eval_select(const uint4* boards, uint32_
 // ------------------------------------------------------------------------------------------------ learning
 
 // QAgent.update (r_learning.py:207-214), one of the 8 images: += dw at every feature slot
+// `dacc` (may be null): the epoch's accumulated weight delta of the multi-GPU scheme — every add to the table is
+// mirrored there (g2048_delta_begin)
 template <int N>
-__device__ __forceinline__ void scatter_image(float* w, const Packed& state, uint32_t g, float dw) {
+__device__ __forceinline__ void scatter_image(float* w, float* dacc, const Packed& state, uint32_t g, float dw) {
     constexpr int F = Shape<N>::F;
     uint32_t s[F];
     feature_slots<N>(d4_image(state, g), s);
 #pragma unroll
     for (int f = 0; f < F; ++f) __hip_atomic_fetch_add(&w[s[f]], dw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (dacc) {
+#pragma unroll
+        for (int f = 0; f < F; ++f) __hip_atomic_fetch_add(&dacc[s[f]], dw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // thread t handles image (t & 7) of record (t >> 3)
 template <int N>
-__global__ __launch_bounds__(WG) void k_update_records(float* w, const uint4* states, const float* dw, uint32_t count) {
+__global__ __launch_bounds__(WG) void k_update_records(float* w, float* dacc, const uint4* states, const float* dw, uint32_t count) {
     uint32_t t = blockIdx.x * WG + threadIdx.x;
     uint32_t rec = t >> 3;
     if (rec >= count) return;
-    scatter_image<N>(w, pack_board(ld_board(states, rec)), t & 7u, dw[rec]);
+    scatter_image<N>(w, dacc, pack_board(ld_board(states, rec)), t & 7u, dw[rec]);
 }
 
 // The (state, dw) records one TD step produces — the arguments of the calls to QAgent.update in QAgent.episode:
@@ -622,6 +639,7 @@ __global__ __launch_bounds__(WG) void k_td_play(uint4* boards, int32_t* scores, 
     const uint32_t base = blk * WG;
     const uint32_t i = base + threadIdx.x;
     bool moved = false;
+    uint32_t ndirs = 0;             // directions that were open to this lane's move
     float dw_big = 0.0f;            // largest |dw| this lane emits
     if (i < B) {
         uint8_t fl = flags[i];
@@ -646,6 +664,7 @@ __global__ __launch_bounds__(WG) void k_td_play(uint4* boards, int32_t* scores, 
                 old_label = c.value;
                 fl |= HAS_PREV;
                 moved = true;
+                ndirs = popcount32(changed_mask(mv));
                 b = ch.after;
                 lm = (uint32_t)c.action | 4u;
                 if (spawn(b, g)) {
@@ -662,8 +681,12 @@ __global__ __launch_bounds__(WG) void k_td_play(uint4* boards, int32_t* scores, 
                 over = game_over(b) || overflow;
                 if (over) {
                     const float dw2 = -c.value * alpha / F;
-                    push_terminal(recs, after, dw2);
-                    dw_big = fabsf(dw2);
+                    if (isfinite(dw2)) {
+                        push_terminal(recs, after, dw2);
+                        dw_big = fabsf(dw2);
+                    } else {
+                        atomicAdd(&ws.nonfinite, 1u);
+                    }
                 }
             } else {
                 // a dead board was loaded: the reference's loop would not run; only the terminal update remains
@@ -671,8 +694,12 @@ __global__ __launch_bounds__(WG) void k_td_play(uint4* boards, int32_t* scores, 
                 prev_nxt[i] = recs.state1[i];
                 if (fl & HAS_PREV) {
                     const float dw2 = -old_label * alpha / F;
-                    push_terminal(recs, ld_packed(recs.state1, i), dw2);
-                    dw_big = fabsf(dw2);
+                    if (isfinite(dw2)) {
+                        push_terminal(recs, ld_packed(recs.state1, i), dw2);
+                        dw_big = fabsf(dw2);
+                    } else {
+                        atomicAdd(&ws.nonfinite, 1u);
+                    }
                 }
             }
             const int32_t final_score = score;
@@ -695,12 +722,18 @@ __global__ __launch_bounds__(WG) void k_td_play(uint4* boards, int32_t* scores, 
             label[i] = old_label;
             flags[i] = fl;
         }
+        // a record whose dw is not finite (a table poisoned with inf / NaN) is dropped and counted: the fixed-point sums
+        // of the LDS-owner update have no encoding for it
+        if (!isfinite(dw1)) {
+            atomicAdd(&ws.nonfinite, 1u);
+            dw1 = 0.0f;
+        }
         recs.dw1[i] = dw1;
         last_move[i] = (uint16_t)lm;
         dw_big = fmaxf(dw_big, fabsf(dw1));
     }
-    if (dw_big > 0.0f && isfinite(dw_big)) atomicMax(&ws.dw_max_bits, __float_as_uint(dw_big));
-    count_moves(&ws, moved ? 1u : 0u);
+    if (dw_big > 0.0f) atomicMax(&ws.dw_max_bits, __float_as_uint(dw_big));
+    count_moves(&ws, moved ? 1u : 0u, ndirs);
     }
     wg_stats_flush(&ws, stats);
     if (threadIdx.x == 0 && ws.dw_max_bits) atomicMax(recs.dwmax, ws.dw_max_bits);
@@ -709,14 +742,14 @@ __global__ __launch_bounds__(WG) void k_td_play(uint4* boards, int32_t* scores, 
 // Step part 2, global-atomics form — QAgent.update for every record: thread t adds image (t & 7) of record (t >> 3);
 // records B .. B + qcount - 1 are the terminal queue.
 template <int N>
-__global__ __launch_bounds__(WG) void k_td_update(float* w, TdRecs recs, uint32_t B) {
+__global__ __launch_bounds__(WG) void k_td_update(float* w, float* dacc, TdRecs recs, uint32_t B) {
     uint32_t t = blockIdx.x * WG + threadIdx.x;
     uint32_t r = t >> 3, g = t & 7u;
     if (r < B) {
         float dw = recs.dw1[r];
-        if (dw != 0.0f) scatter_image<N>(w, ld_packed(recs.state1, r), g, dw);
+        if (dw != 0.0f) scatter_image<N>(w, dacc, ld_packed(recs.state1, r), g, dw);
     } else if (r - B < *recs.qcount) {
-        scatter_image<N>(w, ld_packed(recs.qstate, r - B), g, recs.qdw[r - B]);
+        scatter_image<N>(w, dacc, ld_packed(recs.qstate, r - B), g, recs.qdw[r - B]);
     }
 }
 
@@ -989,7 +1022,11 @@ __global__ __launch_bounds__(OWN_WG) void k_td_update_owner(float* dst, TdRecs r
     if (fixed) {
         const float big = recs.unit ? 1.0f : __uint_as_float(*recs.dwmax);
         int e = big > 0.0f ? ilogbf(big) + 1 : 0;
+        // a slot can take all 4 visited images of every record of this part: |sum| < 4 x records x 2^(e+S) must stay below 2^61
+        const uint32_t part_recs = (B + s.nparts - 1) / s.nparts + *recs.qcount;
+        const int add_bits = 32 - __clz((int)(part_recs < (1u << 29) ? 4u * part_recs : 0x7FFFFFFFu));
         int S = 38 - e;
+        if (S > 61 - e - add_bits) S = 61 - e - add_bits;
         S = S > 100 ? 100 : (S < -60 ? -60 : S);
         scale = ldexpf(1.0f, S);
         inv_scale = ldexpf(1.0f, -S);
@@ -1017,12 +1054,21 @@ __global__ __launch_bounds__(OWN_WG) void k_td_update_owner(float* dst, TdRecs r
     if (threadIdx.x == 0) wg_clock[2 * blockIdx.x + 1] = wall_clock64();
 }
 
+// table_i[perm_i(k)] += v for every member i of the orbit; `dacc` (may be null) mirrors the add (g2048_delta_begin)
+__device__ __forceinline__ void add_to_members(float* w, float* dacc, const OrbitInfo& oi, uint32_t k, float v) {
+    for (uint32_t m = 0; m < oi.nmem; ++m) {
+        const uint32_t slot = oi.off[m] + permute_digits(k, oi.perm[m], oi.digits, oi.radix);
+        w[slot] += v;
+        if (dacc) dacc[slot] += v;
+    }
+}
+
 // D -> every member table of its orbit (plain read-modify-write: for one member the permutation is a bijection, and
 // members are different features, so no two threads touch the same slot), then D is cleared for the next step.
 // The LDS-owned orbit tables [0, owned) are double-buffered (cur: this step's sums, oth: the next step's, cleared here;
 // a clear in place would race with the threads that read E[sigma(k)]; a memset between the steps costs a launch and, in
 // ROCclr, ~20 us of idle queue); the f_6 orbit tables behind them live in D and are cleared in place.
-__global__ __launch_bounds__(WG) void k_apply_orbits(float* w, float* D, const float* cur, float* oth, uint32_t owned, OrbitTable t) {
+__global__ __launch_bounds__(WG) void k_apply_orbits(float* w, float* dacc, float* D, const float* cur, float* oth, uint32_t owned, OrbitTable t) {
     const uint32_t K = blockIdx.x * WG + threadIdx.x;
     if (K >= t.total) return;
     if (K < owned) oth[K] = 0.0f;
@@ -1051,14 +1097,13 @@ __global__ __launch_bounds__(WG) void k_apply_orbits(float* w, float* D, const f
         for (uint32_t s = 1; s < oi.nstab; ++s) v += cur[oi.base + permute_digits(k, oi.sperm[s], oi.digits, oi.radix)];
         if (v == 0.0f) return;
     }
-    for (uint32_t m = 0; m < oi.nmem; ++m) w[oi.off[m] + permute_digits(k, oi.perm[m], oi.digits, oi.radix)] += v;
-    if (k2 != k)
-        for (uint32_t m = 0; m < oi.nmem; ++m) w[oi.off[m] + permute_digits(k2, oi.perm[m], oi.digits, oi.radix)] += v;
+    add_to_members(w, dacc, oi, k, v);
+    if (k2 != k) add_to_members(w, dacc, oi, k2, v);
 }
 
 // Per-slot mean rule (g2048_set_update_rule): S = sum of the dw that target a slot, C = how many did; the slot moves
 // by S / C.  S and C come from two runs of the same accumulation (the second with dw = 1).
-__global__ __launch_bounds__(WG) void k_apply_orbits_mean(float* w, float* S, float* C, const float* scur, const float* ccur, float* soth,
+__global__ __launch_bounds__(WG) void k_apply_orbits_mean(float* w, float* dacc, float* S, float* C, const float* scur, const float* ccur, float* soth,
                                                           float* coth, uint32_t owned, OrbitTable t) {
     const uint32_t K = blockIdx.x * WG + threadIdx.x;
     if (K >= t.total) return;
@@ -1101,19 +1146,31 @@ __global__ __launch_bounds__(WG) void k_apply_orbits_mean(float* w, float* S, fl
         if (cnt == 0.0f) return;
     }
     const float v = sum / cnt;
-    for (uint32_t m = 0; m < oi.nmem; ++m) w[oi.off[m] + permute_digits(k, oi.perm[m], oi.digits, oi.radix)] += v;
-    if (k2 != k)
-        for (uint32_t m = 0; m < oi.nmem; ++m) w[oi.off[m] + permute_digits(k2, oi.perm[m], oi.digits, oi.radix)] += v;
+    add_to_members(w, dacc, oi, k, v);
+    if (k2 != k) add_to_members(w, dacc, oi, k2, v);
 }
 
-__global__ __launch_bounds__(WG) void k_apply_flat_mean(float* w, float* S, float* C, uint32_t slots) {
+__global__ __launch_bounds__(WG) void k_apply_flat_mean(float* w, float* dacc, float* S, float* C, uint32_t slots) {
     const uint32_t K = blockIdx.x * WG + threadIdx.x;
     if (K >= slots) return;
     const float cnt = C[K];
     if (cnt == 0.0f) return;
-    w[K] += S[K] / cnt;
+    const float v = S[K] / cnt;
+    w[K] += v;
+    if (dacc) dacc[K] += v;
     S[K] = 0.0f;
     C[K] = 0.0f;
+}
+
+// n = 2, 3 with delta tracking on: the owner workgroups sum into S instead of the table, and this adds S to both
+__global__ __launch_bounds__(WG) void k_apply_flat_sum(float* w, float* dacc, float* S, uint32_t slots) {
+    const uint32_t K = blockIdx.x * WG + threadIdx.x;
+    if (K >= slots) return;
+    const float v = S[K];
+    if (v == 0.0f) return;
+    w[K] += v;
+    dacc[K] += v;
+    S[K] = 0.0f;
 }
 
 // n = 6: the twelve 14^6-slot tables (361 MB) do not fit in LDS, so their adds end as global atomics — but (1) through
@@ -1184,13 +1241,39 @@ __global__ __launch_bounds__(WG) void k_delta_sub(const float* w, const float* w
     for (; i < count; i += stride) delta[i] = w[i] - w0[i];
 }
 
-__global__ __launch_bounds__(WG) void k_delta_add(float* w, float* w0, const float* delta, uint64_t count) {
+// W = W0 + (delta summed over the ranks); the next epoch starts here: W0 = W, accumulator cleared
+__global__ __launch_bounds__(WG) void k_delta_add(float* w, float* w0, const float* delta, float* dacc, uint64_t count) {
     uint64_t i = (uint64_t)blockIdx.x * WG + threadIdx.x;
     uint64_t stride = (uint64_t)gridDim.x * WG;
     for (; i < count; i += stride) {
         float v = w0[i] + delta[i];
         w[i] = v;
         w0[i] = v;
+        if (dacc) dacc[i] = 0.0f;
+    }
+}
+
+// Per-slot mean rule across ranks: pack = [delta | touched] with touched = 1 where this rank moved the slot in the epoch;
+// after the sum all-reduce the slot moves by the mean over the ranks that touched it.
+__global__ __launch_bounds__(WG) void k_delta_pack_touched(const float* dacc, float* pack, uint64_t count) {
+    uint64_t i = (uint64_t)blockIdx.x * WG + threadIdx.x;
+    uint64_t stride = (uint64_t)gridDim.x * WG;
+    for (; i < count; i += stride) {
+        const float d = dacc[i];
+        pack[i] = d;
+        pack[count + i] = d != 0.0f ? 1.0f : 0.0f;
+    }
+}
+
+__global__ __launch_bounds__(WG) void k_delta_add_mean(float* w, float* w0, const float* pack, float* dacc, uint64_t count) {
+    uint64_t i = (uint64_t)blockIdx.x * WG + threadIdx.x;
+    uint64_t stride = (uint64_t)gridDim.x * WG;
+    for (; i < count; i += stride) {
+        const float n = pack[count + i];
+        float v = w0[i] + (n > 1.0f ? pack[i] / n : pack[i]);
+        w[i] = v;
+        w0[i] = v;
+        dacc[i] = 0.0f;
     }
 }
 
@@ -1229,6 +1312,13 @@ struct g2048_ctx {
     GameLog log = {0, 0, nullptr, nullptr, nullptr};
     uint32_t step_parity = 0;
     float *w = nullptr, *w0 = nullptr, *delta = nullptr;
+    // multi-GPU epoch state (g2048_delta_begin): W0 = table at the start of the epoch; `delta` accumulates every add this
+    // context makes to the table (null until tracking is on); `pack` = all-reduce buffer ([delta | touched] for the mean rule)
+    bool tracking = false;
+    float* pack = nullptr;
+    size_t pack_count = 0;
+    void* comm = nullptr;               // ncclComm_t of g2048_comm_init
+    int comm_rank = 0, comm_ranks = 1;
     Stats* stats = nullptr;
     Slice* slices = nullptr;            // LDS-owner update plan (device copy, capacity MAX_SLICES)
     uint32_t n_slices = 0;
@@ -1236,7 +1326,26 @@ struct g2048_ctx {
     uint32_t n_chunks = 0;
     unsigned play_wgs = 0;          // persistent grid of k_td_play (0 = not determined yet)
     uint32_t owned_total = 0;       // D[0 .. owned_total): the LDS-owned orbit tables (cleared by the host after k_apply_orbits)
-    uint32_t steps_since_plan = 0, replan_every = 8;     // the board distribution drifts with the games' age: follow it closely
+    uint32_t steps_since_plan = 0;  // launches of the owner kernel under the current plan
+    uint32_t steps_since_read = 0;  // ... since the hit counters were last read back
+    uint32_t replan_interval = 1;   // steps until the next unconditional replan: 1, 2, 4, ... replan_every after a (re)start
+    double makespan_ref = 0;        // owner kernel makespan (100 MHz ticks) of the first launch under the current plan
+    bool plan_measured = false;     // the load is a measurement (not the creation-time prior)
+    hipStream_t side = nullptr;     // carries the statistics read-back so that it overlaps k_td_play
+    hipEvent_t ev_upd = nullptr;    // end of a step's update on `stream`
+    hipEvent_t ev_table = nullptr;  // last table-touching launch on `stream` (contexts that share a table wait on it)
+    g2048_ctx* parent = nullptr;    // owner of the shared table (g2048_create_shared); null: this context owns `w`
+    uint32_t shared_users = 0;      // (owner only) contexts created on this table with g2048_create_shared and still alive
+    g2048_ctx* last_user = nullptr; // (owner only) whose stream carried the latest launch that reads or writes the table
+    // experiment knobs (environment, read ONCE at creation): defaults are the measured best
+    struct Knobs {
+        uint32_t replan_every = 8;      // upper end of the replan schedule: the board distribution drifts with the games' age
+        double imbalance = 1.15;        // replan as soon as the owner kernel's makespan exceeds this multiple of makespan_ref
+        int feedback_each_step = 1;     // read the workgroup clocks back after every step (big batches only)
+        double add_cost = 3.0, thr = 0.01, fixed_ratio = 0.25;
+        int plan_feedback = 1, plan_xcd = 1, debug_plan = 0;
+        unsigned play_wgs = 0;
+    } knob;
     std::vector<double> load;           // smoothed adds per step per chunk
     std::vector<double> work;           // measured workgroup time x workgroups per chunk (clock ticks; 0 = not measured yet)
     float* D = nullptr;                 // per-orbit delta tables (n >= 4; mean rule: also the sums for n = 2, 3)
@@ -1284,6 +1393,45 @@ int fail(g2048_ctx* c, int code, const char* what, hipError_t e = hipSuccess) {
     } while (0)
 
 inline unsigned grid_for(uint64_t threads) { return (unsigned)((threads + WG - 1) / WG); }
+
+// Contexts that share a weight table (g2048_create_shared) run on their own streams.  The caller serialises its CALLS on
+// such contexts; these two order the DEVICE work behind them: before a context's launches read or write the table its
+// stream waits for the latest launch any other context made on it (an event on the owner, re-recorded after every use).
+// With no sharing this is free.
+g2048_ctx* table_root(g2048_ctx* c) { return c->parent ? c->parent : c; }
+struct TableUse {
+    g2048_ctx* c;
+    int rc = G2048_OK;
+    explicit TableUse(g2048_ctx* ctx) : c(ctx) {
+        g2048_ctx* r = table_root(c);
+        if (r->shared_users && r->last_user && r->last_user != c && hipStreamWaitEvent(c->stream, r->ev_table, 0) != hipSuccess) {
+            c->err = "hipStreamWaitEvent(table)";
+            rc = G2048_ERR_HIP;
+        }
+    }
+    ~TableUse() {
+        g2048_ctx* r = table_root(c);
+        if (rc == G2048_OK && r->shared_users && hipEventRecord(r->ev_table, c->stream) == hipSuccess) r->last_user = c;
+    }
+};
+#define USE_TABLE(c)            \
+    TableUse table_use_(c);     \
+    if (table_use_.rc) return table_use_.rc
+
+// experiment knobs: the environment is read once, when a context is created
+void read_knobs(g2048_ctx* c) {
+    g2048_ctx::Knobs& k = c->knob;
+    if (const char* e = getenv("G2048_REPLAN_EVERY")) k.replan_every = (uint32_t)std::max(1, atoi(e));
+    if (const char* e = getenv("G2048_PLAN_IMBALANCE")) k.imbalance = atof(e);
+    if (const char* e = getenv("G2048_PLAN_EACH_STEP")) k.feedback_each_step = atoi(e);
+    if (const char* e = getenv("G2048_PLAN_FIXEDRATIO")) k.fixed_ratio = atof(e);
+    if (const char* e = getenv("G2048_PLAN_ADDCOST")) k.add_cost = atof(e);
+    if (const char* e = getenv("G2048_PLAN_THR")) k.thr = atof(e);
+    if (const char* e = getenv("G2048_PLAN_FEEDBACK")) k.plan_feedback = atoi(e);
+    if (const char* e = getenv("G2048_PLAN_XCD")) k.plan_xcd = atoi(e);
+    if (getenv("G2048_DEBUG_PLAN")) k.debug_plan = 1;
+    if (const char* e = getenv("G2048_PLAY_WGS")) k.play_wgs = (unsigned)atoi(e);
+}
 
 int bind(g2048_ctx* c) {
     HIP_TRY(c, hipSetDevice(c->device));
@@ -1544,7 +1692,7 @@ int build_slices(g2048_ctx* c) {
     const size_t nc = chunks.size();
     if (nc == 0) return fail(c, G2048_ERR_STATE, "unexpected orbit structure");
     if (nc > HITS_CAP) return fail(c, G2048_ERR_STATE, "more chunks than hit counters");
-    if (!c->n_chunks && getenv("G2048_DEBUG_PLAN"))
+    if (!c->n_chunks && c->knob.debug_plan)
         for (uint32_t o = 0; o < c->orbits.count; ++o) {
             const OrbitInfo& oi = c->orbits.o[o];
             fprintf(stderr, "[g2048 orbit %u] base %u size %u members:", o, oi.base, oi.size);
@@ -1565,10 +1713,7 @@ int build_slices(g2048_ctx* c) {
             c->load[k] = 8.0 * c->B * share * (c->n == 2 ? 24 : c->n == 3 ? (chunks[k].size / 4096.0) : 1);
         }
     }
-    double add_cost = 3.0, thr = 0.01, fixed_ratio = 0.25;
-    if (const char* e = getenv("G2048_PLAN_FIXEDRATIO")) fixed_ratio = atof(e);
-    if (const char* e = getenv("G2048_PLAN_ADDCOST")) add_cost = atof(e);      // (experiments)
-    if (const char* e = getenv("G2048_PLAN_THR")) thr = atof(e);
+    const double add_cost = c->knob.add_cost, thr = c->knob.thr, fixed_ratio = c->knob.fixed_ratio;
     const double B = c->B;
     // which chunks get LDS workgroups: those with at least `thr` of their orbit's adds, and each orbit's busiest
     std::vector<char> in_lds(nc, 1);
@@ -1602,8 +1747,7 @@ int build_slices(g2048_ctx* c) {
         }
     // Feedback: where the last launches were timed (per-workgroup clocks, see replan), a chunk's cost is its measured
     // work; chunks without a measurement (they had no workgroup yet) keep the model's cost, scaled to the same unit.
-    bool use_work = c->work.size() == nc && c->n >= 4;
-    if (const char* e = getenv("G2048_PLAN_FEEDBACK")) use_work = use_work && atoi(e) != 0;
+    const bool use_work = c->work.size() == nc && c->n >= 4 && c->knob.plan_feedback != 0;
     if (use_work) {
         double measured = 0, modelled = 0;
         for (size_t k = 0; k < nc; ++k)
@@ -1629,7 +1773,7 @@ int build_slices(g2048_ctx* c) {
     // 0: flat plan; 1 (default where it applies): XCD-resident scan.  (Cutting the chunks into pieces packed onto the 32
     // workgroups of an XCD, a workgroup running its pieces one after the other, was tried: 0.296 -> 0.311 ms per step.)
     int xcd_plan = (c->n >= 4 && c->B >= (1u << 17) && n_lds <= CUS_PER_XCD) ? 1 : 0;
-    if (const char* e = getenv("G2048_PLAN_XCD")) xcd_plan = xcd_plan ? atoi(e) : 0;
+    if (!c->knob.plan_xcd) xcd_plan = 0;
     if (xcd_plan == 1) {
         // XCD-resident scan.  Workgroup i runs on XCD i % 8 and every XCD has its own 4 MB L2.  The records are cut into 8
         // ranges; range x is scanned only by the workgroups of XCD x (every chunk gets the same number of workgroups on each
@@ -1669,7 +1813,7 @@ int build_slices(g2048_ctx* c) {
     if (v.size() > MAX_SLICES) return fail(c, G2048_ERR_STATE, "LDS-owner plan too large");
     c->n_slices = (uint32_t)v.size();
     c->plan = v;
-    if (getenv("G2048_DEBUG_PLAN")) {
+    if (c->knob.debug_plan) {
         fprintf(stderr, "[g2048 plan] %zu workgroups over %zu chunks; (chunk:load/parts)", v.size(), nc);
         for (size_t k = 0; k < nc; ++k) fprintf(stderr, " %zu:%.3f/%u", k, c->load[k] / (8.0 * B), parts[k]);
         fprintf(stderr, "\n");
@@ -1679,22 +1823,29 @@ int build_slices(g2048_ctx* c) {
     memcpy(c->h_slices, v.data(), v.size() * sizeof(Slice));
     HIP_TRY(c, hipMemcpyAsync(c->slices, c->h_slices, v.size() * sizeof(Slice), hipMemcpyHostToDevice, c->stream));
     c->steps_since_plan = 0;
+    c->makespan_ref = 0;
     return G2048_OK;
 }
 
-// Replan, first half (BEFORE the step's k_td_play is launched): one copy into pinned memory brings the hit counters and
-// the workgroup clocks of the steps so far.
-int replan_readback(g2048_ctx* c) {
-    if (c->n < 4 || c->n_chunks == 0 || c->steps_since_plan == 0) return G2048_OK;
-    HIP_TRY(c, hipMemcpyAsync(c->h_stat, c->statbuf, STAT_BYTES, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipEventRecord(c->ev_plan, c->stream));
+// Planner feedback, first half (BEFORE the step's k_td_play is launched): the hit counters and the workgroup clocks of
+// the update launches so far are copied into pinned memory on the SIDE stream, behind the previous step's update, so
+// that the copy runs beside k_td_play instead of in front of it.
+int stats_readback(g2048_ctx* c) {
+    if (c->n < 4 || c->n_chunks == 0 || c->steps_since_read == 0) return G2048_OK;
+    HIP_TRY(c, hipEventRecord(c->ev_upd, c->stream));
+    HIP_TRY(c, hipStreamWaitEvent(c->side, c->ev_upd, 0));
+    HIP_TRY(c, hipMemcpyAsync(c->h_stat, c->statbuf, STAT_BYTES, hipMemcpyDeviceToHost, c->side));
+    HIP_TRY(c, hipEventRecord(c->ev_plan, c->side));
     c->plan_pending = true;
     return G2048_OK;
 }
 
 // Second half (AFTER k_td_play is launched, before the update's launch): wait for that copy — the GPU is busy with
-// k_td_play for ~0.2 ms meanwhile, so it does not idle while the host folds the counters into the smoothed load,
-// rebuilds the plan (tens of microseconds) and queues its upload.
+// k_td_play for ~0.2 ms meanwhile — fold the counters into the load and the clocks into the per-chunk work, and rebuild
+// the plan when it is due (1, 2, 4, ... replan_every steps after a start: the creation-time prior is wrong for whatever
+// the boards look like, and one measured launch is enough to correct it) or when the last launch's makespan has grown
+// past `imbalance` x what the plan achieved on its first launch (young synchronised boards change their tile
+// distribution from one step to the next).
 int replan(g2048_ctx* c) {
     if (!c->plan_pending) return G2048_OK;
     c->plan_pending = false;
@@ -1703,20 +1854,28 @@ int replan(g2048_ctx* c) {
     for (size_t k = 0; k < c->n_chunks; ++k) {
         const uint32_t fresh = h[k] - c->hits_seen[k];          // cumulative counters, modulo 2^32
         c->hits_seen[k] = h[k];
-        c->load[k] = 0.5 * c->load[k] + 0.5 * (double)fresh / c->steps_since_plan;
+        const double per_step = (double)fresh / c->steps_since_read;
+        c->load[k] = c->plan_measured ? 0.5 * c->load[k] + 0.5 * per_step : per_step;
     }
+    c->plan_measured = true;
+    c->steps_since_read = 0;
     // the last launch's workgroup clocks: work of a chunk = (mean duration - fixed part) x its workgroups
+    double makespan = 0;
     if (c->plan.size() == c->n_slices && c->n_slices) {
         const uint64_t* clk = reinterpret_cast<const uint64_t*>(c->h_stat + HITS_CAP * 4);
         const double fixed_ticks = 300.0;                   // LDS clear + flush, ~3 us of the 100 MHz clock
         std::vector<double> sum(c->n_chunks, 0.0);
         std::vector<uint32_t> cnt(c->n_chunks, 0);
+        uint64_t first = ~0ull, last = 0;
         for (uint32_t i = 0; i < c->n_slices; ++i) {
             const uint64_t a = clk[2 * i], b = clk[2 * i + 1];
             if (b <= a || b - a > 100000000ull || c->plan[i].chunk >= c->n_chunks) continue;      // (never launched / garbage)
             sum[c->plan[i].chunk] += (double)(b - a);
             ++cnt[c->plan[i].chunk];
+            first = a < first ? a : first;
+            last = b > last ? b : last;
         }
+        if (last > first && last - first < 100000000ull) makespan = (double)(last - first);
         if (c->work.size() != c->n_chunks) c->work.assign(c->n_chunks, 0.0);
         for (uint32_t k = 0; k < c->n_chunks; ++k) {
             if (!cnt[k]) {
@@ -1728,6 +1887,14 @@ int replan(g2048_ctx* c) {
             c->work[k] = c->work[k] > 0 ? 0.5 * c->work[k] + 0.5 * w : w;
         }
     }
+    const bool due = c->steps_since_plan >= c->replan_interval;
+    const bool skew = c->makespan_ref > 0 && makespan > c->knob.imbalance * c->makespan_ref;
+    if (c->makespan_ref == 0) c->makespan_ref = makespan;       // first measured launch under this plan
+    if (c->knob.debug_plan)
+        fprintf(stderr, "[g2048 feedback] steps under plan %u makespan %.1f us (ref %.1f)%s%s\n", c->steps_since_plan, makespan * 0.01,
+                c->makespan_ref * 0.01, due ? " due" : "", skew ? " skew" : "");
+    if (!due && !skew) return G2048_OK;
+    if (due) c->replan_interval = std::min(c->replan_interval * 2u, std::max(1u, c->knob.replan_every));
     return build_slices(c);
 }
 
@@ -1739,7 +1906,7 @@ unsigned play_grid(g2048_ctx* c) {
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_td_play<N>, WG, 0) != hipSuccess || per_cu <= 0) per_cu = 2;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || cus <= 0) cus = 256;
         c->play_wgs = (unsigned)(per_cu * cus);
-        if (const char* e = getenv("G2048_PLAY_WGS")) c->play_wgs = (unsigned)atoi(e);       // (experiments)
+        if (c->knob.play_wgs) c->play_wgs = c->knob.play_wgs;                                 // (experiments)
     }
     const unsigned need = grid_for(c->B);
     return need < c->play_wgs ? need : c->play_wgs;
@@ -1747,7 +1914,7 @@ unsigned play_grid(g2048_ctx* c) {
 
 // One TD step on the context's stream: k_td_play, then the update in the selected mode.  `ev` (optional) gets an
 // event between the two parts.
-int launch_td_step(g2048_ctx* c, float alpha, hipEvent_t ev = nullptr) {
+int launch_td_step(g2048_ctx* c, float alpha, hipEvent_t ev = nullptr, hipEvent_t ev_owner = nullptr, hipEvent_t ev_tail = nullptr) {
     const uint32_t B = c->B;
     uint4* pn = c->prev[c->cur ^ 1];
     TdRecs recs;
@@ -1765,9 +1932,9 @@ int launch_td_step(g2048_ctx* c, float alpha, hipEvent_t ev = nullptr) {
     recs.oidx = c->oidx[c->cur];
     recs.oidx_nxt = c->oidx[c->cur ^ 1];
     if (c->update_mode == 1) {
-        if (const char* e = getenv("G2048_REPLAN_EVERY")) c->replan_every = (uint32_t)atoi(e);       // (experiments)
-        if (c->steps_since_plan >= c->replan_every)
-            if (int rc = replan_readback(c)) return rc;
+        const bool each = c->knob.feedback_each_step && B >= (1u << 17);
+        if (each || c->steps_since_plan >= c->replan_interval)
+            if (int rc = stats_readback(c)) return rc;
     }
     BY_N(c, (k_td_play<N><<<play_grid<N>(c), WG, 0, c->stream>>>(c->boards, c->scores, c->rng, pn, c->label, c->flags, B, c->w, alpha, recs,
                                                              c->auto_reset, c->stats, c->last_move, c->log)));
@@ -1775,6 +1942,7 @@ int launch_td_step(g2048_ctx* c, float alpha, hipEvent_t ev = nullptr) {
     if (c->update_mode == 1) {
         if (int rc = replan(c)) return rc;
         ++c->steps_since_plan;
+        ++c->steps_since_read;
         const uint32_t tail_grid = B >= (1u << 16) ? 512 : 16;
         recs.unit = 0;
         // n >= 4: the LDS-owned orbit tables are double-buffered (k_apply_orbits clears the other one for the next step)
@@ -1783,27 +1951,36 @@ int launch_td_step(g2048_ctx* c, float alpha, hipEvent_t ev = nullptr) {
         float* Doth = alt ? c->D : c->D2;
         float* Ccur = alt ? c->Dcnt2 : c->Dcnt;
         float* Coth = alt ? c->Dcnt : c->Dcnt2;
+        float* dacc = c->tracking ? c->delta : nullptr;
         if (c->update_rule == 1) {      // counting pass: the same accumulation with dw = 1, into Dcnt
             TdRecs ones = recs;
             ones.unit = 1;
             BY_N(c, (k_td_update_owner<N><<<c->n_slices, OWN_WG, 0, c->stream>>>(Ccur, ones, B, c->slices, c->hits, c->wg_clock)));
             if (c->n == 6) k_td_update_tail<6><<<tail_grid, OWN_WG, 0, c->stream>>>(c->Dcnt, ones, B, c->orbits.o[6].base, c->orbits.o[7].base);
         }
-        float* dst = c->n >= 4 ? Dcur : (c->update_rule == 1 ? c->D : c->w);
+        // n = 2, 3: the workgroups add straight into the table, unless the sums are needed apart (mean rule, delta tracking)
+        const bool flat_apart = c->n < 4 && (c->update_rule == 1 || dacc);
+        float* dst = c->n >= 4 ? Dcur : (flat_apart ? c->D : c->w);
         BY_N(c, (k_td_update_owner<N><<<c->n_slices, OWN_WG, 0, c->stream>>>(dst, recs, B, c->slices, c->hits, c->wg_clock)));
+        if (ev_owner) (void)hipEventRecord(ev_owner, c->stream);
         if (c->n == 6) k_td_update_tail<6><<<tail_grid, OWN_WG, 0, c->stream>>>(c->D, recs, B, c->orbits.o[6].base, c->orbits.o[7].base);
+        if (ev_tail) (void)hipEventRecord(ev_tail, c->stream);
         if (c->update_rule == 1) {
             if (c->n >= 4)
-                k_apply_orbits_mean<<<grid_for(c->orbits.total), WG, 0, c->stream>>>(c->w, c->D, c->Dcnt, Dcur, Ccur, Doth, Coth, c->owned_total,
+                k_apply_orbits_mean<<<grid_for(c->orbits.total), WG, 0, c->stream>>>(c->w, dacc, c->D, c->Dcnt, Dcur, Ccur, Doth, Coth, c->owned_total,
                                                                                         c->orbits);
             else
-                k_apply_flat_mean<<<grid_for(c->slots), WG, 0, c->stream>>>(c->w, c->D, c->Dcnt, (uint32_t)c->slots);
+                k_apply_flat_mean<<<grid_for(c->slots), WG, 0, c->stream>>>(c->w, dacc, c->D, c->Dcnt, (uint32_t)c->slots);
         } else if (c->n >= 4) {
-            k_apply_orbits<<<grid_for(c->orbits.total), WG, 0, c->stream>>>(c->w, c->D, Dcur, Doth, c->owned_total, c->orbits);
+            k_apply_orbits<<<grid_for(c->orbits.total), WG, 0, c->stream>>>(c->w, dacc, c->D, Dcur, Doth, c->owned_total, c->orbits);
+        } else if (flat_apart) {
+            k_apply_flat_sum<<<grid_for(c->slots), WG, 0, c->stream>>>(c->w, dacc, c->D, (uint32_t)c->slots);
         }
         if (c->n >= 4) c->dpar ^= 1u;
     } else {
-        BY_N(c, (k_td_update<N><<<grid_for((uint64_t)B * 16), WG, 0, c->stream>>>(c->w, recs, B)));
+        BY_N(c, (k_td_update<N><<<grid_for((uint64_t)B * 16), WG, 0, c->stream>>>(c->w, c->tracking ? c->delta : nullptr, recs, B)));
+        if (ev_owner) (void)hipEventRecord(ev_owner, c->stream);
+        if (ev_tail) (void)hipEventRecord(ev_tail, c->stream);
     }
     c->cur ^= 1;
     c->step_parity ^= 1u;
@@ -1836,6 +2013,7 @@ const char* g2048_strerror(int s) {
         case G2048_ERR_NOMEM: return "out of memory";
         case G2048_ERR_STATE: return "invalid state for this call";
         case G2048_ERR_NODEV: return "no usable GPU";
+        case G2048_ERR_COMM: return "RCCL error";
         default: return "unknown status";
     }
 }
@@ -1877,14 +2055,25 @@ int g2048_destroy(g2048_ctx* c) {
     if (!c) return G2048_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->comm) (void)g2048_comm_destroy(c);
+    if (c->parent) {            // the stream is drained: nothing of this context is pending on the shared table
+        if (c->parent->shared_users) --c->parent->shared_users;
+        if (c->parent->last_user == c) c->parent->last_user = nullptr;
+    }
     void* bufs[] = {c->log.moves, c->log.start, c->log.meta, c->boards, c->scores, c->rng, c->prev[0], c->prev[1], c->oidx[0], c->oidx[1], c->label, c->flags, c->dw1, c->qstate,
-                    c->qdw,    c->qcount, c->last_move, c->w,      c->w0,  c->delta,   c->stats,   c->scratch, c->slices, c->statbuf, c->D, c->Dcnt, c->D2, c->Dcnt2};
+                    c->qdw,    c->qcount, c->last_move, c->w,      c->w0,  c->delta,   c->stats,   c->scratch, c->slices, c->statbuf, c->D, c->Dcnt, c->D2, c->Dcnt2, c->pack};
     for (void* p : bufs)
         if (p && (p != (void*)c->w || c->owns_table)) (void)hipFree(p);
     if (c->h_stat) (void)hipHostFree(c->h_stat);
     if (c->h_slices) (void)hipHostFree(c->h_slices);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev_plan) (void)hipEventDestroy(c->ev_plan);
+    if (c->ev_upd) (void)hipEventDestroy(c->ev_upd);
+    if (c->ev_table) (void)hipEventDestroy(c->ev_table);
+    if (c->side) {
+        (void)hipStreamSynchronize(c->side);
+        (void)hipStreamDestroy(c->side);
+    }
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1919,10 +2108,15 @@ static int create_impl(int device, uint32_t batch, int n_tuple, uint64_t seed, u
         return code;
     };
     if (hipSetDevice(device) != hipSuccess) return bail(G2048_ERR_HIP);
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail(G2048_ERR_HIP);
-    if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_plan, hipEventDisableTiming) != hipSuccess)
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess)
         return bail(G2048_ERR_HIP);
+    if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_plan, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_upd, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_table, hipEventDisableTiming) != hipSuccess)
+        return bail(G2048_ERR_HIP);
+    read_knobs(c);
     const size_t B = batch;
     if ((rc = dalloc(c, &c->boards, B)) || (rc = dalloc(c, &c->scores, B)) || (rc = dalloc(c, &c->rng, B)) ||
         (rc = dalloc(c, &c->prev[0], B)) || (rc = dalloc(c, &c->prev[1], B)) || (rc = dalloc(c, &c->label, B)) ||
@@ -1932,8 +2126,14 @@ static int create_impl(int device, uint32_t batch, int n_tuple, uint64_t seed, u
         return bail(rc);
     if (n_tuple >= 4 && ((rc = dalloc(c, &c->oidx[0], OIDX_BYTES_PER_LANE * B)) || (rc = dalloc(c, &c->oidx[1], OIDX_BYTES_PER_LANE * B)))) return bail(rc);
     if (parent) {
-        c->w = parent->w;
+        g2048_ctx* root = parent->parent ? parent->parent : parent;
+        c->w = root->w;
         c->owns_table = false;
+        c->parent = root;
+        // whatever the owner has queued on the table so far (weights_init, td_steps ...) comes first
+        if (hipEventRecord(root->ev_table, root->stream) != hipSuccess) return bail(G2048_ERR_HIP);
+        if (!root->last_user) root->last_user = root;
+        ++root->shared_users;
     } else if (slots && (rc = dalloc(c, &c->w, slots))) {
         return bail(rc);
     }
@@ -2033,6 +2233,7 @@ int g2048_clear_carry(g2048_ctx* c) {
 int g2048_reset(g2048_ctx* c) {
     if (!c) return G2048_ERR_ARG;
     if (int rc = bind(c)) return rc;
+    c->replan_interval = 1;         // the tile distribution restarts: follow it closely again
     k_new_games<<<grid_for(c->B), WG, 0, c->stream>>>(c->boards, c->scores, c->rng, c->label, c->flags, c->B);
     if (c->log.lanes) k_log_init<<<grid_for(c->log.lanes), WG, 0, c->stream>>>(c->log, c->boards, c->flags);
     return launched(c, "k_new_games");
@@ -2142,6 +2343,7 @@ int g2048_boards_evaluate(g2048_ctx* c, const uint8_t* boards, int64_t count, fl
     NEED(c, count >= 0 && count <= (1 << 28), "bad board count");
     if (count == 0) return G2048_OK;
     if (int rc = bind(c)) return rc;
+    USE_TABLE(c);
     const size_t n = (size_t)count;
     if (int rc = ensure_scratch(c, n * 20)) return rc;
     uint4* d_boards = (uint4*)c->scratch;
@@ -2176,6 +2378,7 @@ int g2048_weights_set(g2048_ctx* c, const float* w, int64_t count) {
     NEED_TABLE(c);
     NEED(c, count == (int64_t)c->slots, "weight count does not match the table");
     if (int rc = bind(c)) return rc;
+    USE_TABLE(c);
     return h2d(c, c->w, w, c->slots * 4);
 }
 
@@ -2184,6 +2387,7 @@ int g2048_weights_get(g2048_ctx* c, float* w, int64_t count) {
     NEED_TABLE(c);
     NEED(c, count == (int64_t)c->slots, "weight count does not match the table");
     if (int rc = bind(c)) return rc;
+    USE_TABLE(c);
     return d2h(c, w, c->w, c->slots * 4);
 }
 
@@ -2191,6 +2395,7 @@ int g2048_weights_init(g2048_ctx* c, uint64_t seed, float scale) {
     if (!c) return G2048_ERR_ARG;
     NEED_TABLE(c);
     if (int rc = bind(c)) return rc;
+    USE_TABLE(c);
     k_weights_init<<<2048, WG, 0, c->stream>>>(c->w, c->slots, seed, scale);
     return launched(c, "k_weights_init");
 }
@@ -2199,6 +2404,7 @@ int g2048_evaluate(g2048_ctx* c, float* value) {
     if (!c || !value) return c ? fail(c, G2048_ERR_ARG, "null buffer") : G2048_ERR_ARG;
     NEED_TABLE(c);
     if (int rc = bind(c)) return rc;
+    USE_TABLE(c);
     if (int rc = ensure_scratch(c, (size_t)c->B * 4)) return rc;
     BY_N(c, (k_evaluate<N><<<grid_for(c->B), WG, 0, c->stream>>>(c->boards, c->B, c->w, (float*)c->scratch)));
     if (int rc = launched(c, "k_evaluate")) return rc;
@@ -2209,6 +2415,7 @@ int g2048_eval_select(g2048_ctx* c, float* value, uint8_t* action, float* values
     if (!c || ((value == nullptr) != (action == nullptr))) return c ? fail(c, G2048_ERR_ARG, "null buffer") : G2048_ERR_ARG;
     NEED_TABLE(c);
     if (int rc = bind(c)) return rc;
+    USE_TABLE(c);
     const size_t B = c->B;
     if (int rc = ensure_scratch(c, B * (16 + 4 + 1))) return rc;
     float4* d_v4 = (float4*)c->scratch;
@@ -2229,13 +2436,14 @@ int g2048_update(g2048_ctx* c, const uint8_t* states, const float* dw, int64_t c
     NEED(c, count >= 0 && count <= (1 << 28), "bad record count");
     if (count == 0) return G2048_OK;
     if (int rc = bind(c)) return rc;
+    USE_TABLE(c);
     const size_t n = (size_t)count;
     if (int rc = ensure_scratch(c, n * 20)) return rc;
     uint4* d_states = (uint4*)c->scratch;
     float* d_dw = (float*)((char*)c->scratch + n * 16);
     int rc;
     if ((rc = h2d(c, d_states, states, n * 16)) || (rc = h2d(c, d_dw, dw, n * 4))) return rc;
-    BY_N(c, (k_update_records<N><<<grid_for(n * 8), WG, 0, c->stream>>>(c->w, d_states, d_dw, (uint32_t)n)));
+    BY_N(c, (k_update_records<N><<<grid_for(n * 8), WG, 0, c->stream>>>(c->w, c->tracking ? c->delta : nullptr, d_states, d_dw, (uint32_t)n)));
     if ((rc = launched(c, "k_update_records"))) return rc;
     return g2048_sync(c);
 }
@@ -2244,6 +2452,7 @@ int g2048_td_steps(g2048_ctx* c, float alpha, uint32_t nsteps) {
     if (!c) return G2048_ERR_ARG;
     NEED_TABLE(c);
     if (int rc = bind(c)) return rc;
+    USE_TABLE(c);
     for (uint32_t s = 0; s < nsteps; ++s)
         if (int rc = launch_td_step(c, alpha)) return rc;
     return launched(c, "k_td_play/k_td_update");
@@ -2287,30 +2496,41 @@ int g2048_set_update_rule(g2048_ctx* c, int rule) {
     return G2048_OK;
 }
 
-int g2048_td_steps_profiled(g2048_ctx* c, float alpha, uint32_t nsteps, float* ms_play, float* ms_update) {
-    if (!c || !ms_play || !ms_update) return c ? fail(c, G2048_ERR_ARG, "null buffer") : G2048_ERR_ARG;
+// average milliseconds per launch: [0] k_td_play, [1] k_td_update_owner (both passes under the mean rule; k_td_update in
+// update mode 0), [2] k_td_update_tail (n = 6, else 0), [3] k_apply_* — HIP events on the context's stream, one wait per step
+int g2048_td_steps_kernel_ms(g2048_ctx* c, float alpha, uint32_t nsteps, float* out4) {
+    if (!c || !out4) return c ? fail(c, G2048_ERR_ARG, "null buffer") : G2048_ERR_ARG;
     NEED_TABLE(c);
     if (int rc = bind(c)) return rc;
-    hipEvent_t e[3];
+    USE_TABLE(c);
+    hipEvent_t e[5];
     for (auto& ev : e) HIP_TRY(c, hipEventCreate(&ev));
-    double tp = 0, tu = 0;
+    double t[4] = {0, 0, 0, 0};
     int rc = G2048_OK;
     for (uint32_t s = 0; s < nsteps && rc == G2048_OK; ++s) {
         (void)hipEventRecord(e[0], c->stream);
-        rc = launch_td_step(c, alpha, e[1]);
-        (void)hipEventRecord(e[2], c->stream);
-        float a = 0, b = 0;
-        if (hipEventSynchronize(e[2]) != hipSuccess || hipEventElapsedTime(&a, e[0], e[1]) != hipSuccess ||
-            hipEventElapsedTime(&b, e[1], e[2]) != hipSuccess)
-            rc = fail(c, G2048_ERR_HIP, "event timing failed");
-        tp += a;
-        tu += b;
+        rc = launch_td_step(c, alpha, e[1], e[2], e[3]);
+        (void)hipEventRecord(e[4], c->stream);
+        if (hipEventSynchronize(e[4]) != hipSuccess) rc = fail(c, G2048_ERR_HIP, "event timing failed");
+        for (int j = 0; j < 4 && rc == G2048_OK; ++j) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, e[j], e[j + 1]) != hipSuccess) rc = fail(c, G2048_ERR_HIP, "event timing failed");
+            t[j] += ms;
+        }
     }
     for (auto& ev : e) (void)hipEventDestroy(ev);
     if (rc) return rc;
-    *ms_play = nsteps ? (float)(tp / nsteps) : 0.0f;
-    *ms_update = nsteps ? (float)(tu / nsteps) : 0.0f;
+    for (int j = 0; j < 4; ++j) out4[j] = nsteps ? (float)(t[j] / nsteps) : 0.0f;
     return launched(c, "k_td_play/k_td_update");
+}
+
+int g2048_td_steps_profiled(g2048_ctx* c, float alpha, uint32_t nsteps, float* ms_play, float* ms_update) {
+    if (!c || !ms_play || !ms_update) return c ? fail(c, G2048_ERR_ARG, "null buffer") : G2048_ERR_ARG;
+    float t[4];
+    if (int rc = g2048_td_steps_kernel_ms(c, alpha, nsteps, t)) return rc;
+    *ms_play = t[0];
+    *ms_update = t[1] + t[2] + t[3];
+    return G2048_OK;
 }
 
 int g2048_debug_owner_plan(g2048_ctx* c, uint64_t* out, uint32_t capacity, uint32_t* count) {
@@ -2401,26 +2621,47 @@ int g2048_weights_device_ptr(g2048_ctx* c, void** ptr, int64_t* count) {
 static int ensure_delta(g2048_ctx* c) {
     int rc;
     if (!c->w0 && (rc = dalloc(c, &c->w0, c->slots))) return rc;
-    if (!c->delta && (rc = dalloc(c, &c->delta, c->slots))) return rc;
+    if (!c->delta) {
+        if ((rc = dalloc(c, &c->delta, c->slots))) return rc;
+        HIP_TRY(c, hipMemsetAsync(c->delta, 0, c->slots * 4, c->stream));
+    }
+    if (c->n < 4 && !c->D) {            // n = 2, 3: the owner workgroups then sum into D instead of the table (k_apply_flat_sum)
+        if ((rc = dalloc(c, &c->D, c->slots))) return rc;
+        HIP_TRY(c, hipMemsetAsync(c->D, 0, c->slots * 4, c->stream));
+    }
+    return G2048_OK;
+}
+
+static int ensure_pack(g2048_ctx* c, size_t count) {
+    if (c->pack && c->pack_count >= count) return G2048_OK;
+    if (c->pack) HIP_TRY(c, hipFree(c->pack));
+    c->pack = nullptr;
+    c->pack_count = 0;
+    if (int rc = dalloc(c, &c->pack, count)) return rc;
+    c->pack_count = count;
     return G2048_OK;
 }
 
 int g2048_delta_begin(g2048_ctx* c) {
     if (!c) return G2048_ERR_ARG;
     NEED_TABLE(c);
+    if (c->parent) return fail(c, G2048_ERR_STATE, "delta tracking belongs to the context that owns the table");
     if (int rc = bind(c)) return rc;
+    USE_TABLE(c);
     if (int rc = ensure_delta(c)) return rc;
     HIP_TRY(c, hipMemcpyAsync(c->w0, c->w, c->slots * 4, hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->delta, 0, c->slots * 4, c->stream));
+    c->tracking = true;
     return G2048_OK;
 }
 
 int g2048_delta_extract(g2048_ctx* c, void* dst) {
     if (!c) return G2048_ERR_ARG;
     NEED_TABLE(c);
-    if (!c->w0) return fail(c, G2048_ERR_STATE, "g2048_delta_begin was not called");
+    if (!c->tracking) return fail(c, G2048_ERR_STATE, "g2048_delta_begin was not called");
     if (int rc = bind(c)) return rc;
-    k_delta_sub<<<2048, WG, 0, c->stream>>>(c->w, c->w0, dst ? (float*)dst : c->delta, c->slots);
-    if (int rc = launched(c, "k_delta_sub")) return rc;
+    USE_TABLE(c);
+    if (dst) HIP_TRY(c, hipMemcpyAsync(dst, c->delta, c->slots * 4, hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return G2048_OK;
 }
@@ -2428,10 +2669,35 @@ int g2048_delta_extract(g2048_ctx* c, void* dst) {
 int g2048_delta_apply(g2048_ctx* c, const void* src) {
     if (!c) return G2048_ERR_ARG;
     NEED_TABLE(c);
-    if (!c->w0) return fail(c, G2048_ERR_STATE, "g2048_delta_begin was not called");
+    if (!c->tracking) return fail(c, G2048_ERR_STATE, "g2048_delta_begin was not called");
     if (int rc = bind(c)) return rc;
-    k_delta_add<<<2048, WG, 0, c->stream>>>(c->w, c->w0, src ? (const float*)src : c->delta, c->slots);
+    USE_TABLE(c);
+    k_delta_add<<<2048, WG, 0, c->stream>>>(c->w, c->w0, src ? (const float*)src : c->delta, c->delta, c->slots);
     if (int rc = launched(c, "k_delta_add")) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return G2048_OK;
+}
+
+int g2048_delta_apply_mean(g2048_ctx* c, const void* pack) {
+    if (!c || !pack) return c ? fail(c, G2048_ERR_ARG, "null buffer") : G2048_ERR_ARG;
+    NEED_TABLE(c);
+    if (!c->tracking) return fail(c, G2048_ERR_STATE, "g2048_delta_begin was not called");
+    if (int rc = bind(c)) return rc;
+    USE_TABLE(c);
+    k_delta_add_mean<<<2048, WG, 0, c->stream>>>(c->w, c->w0, (const float*)pack, c->delta, c->slots);
+    if (int rc = launched(c, "k_delta_add_mean")) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return G2048_OK;
+}
+
+int g2048_delta_pack_touched(g2048_ctx* c, void* pack) {
+    if (!c || !pack) return c ? fail(c, G2048_ERR_ARG, "null buffer") : G2048_ERR_ARG;
+    NEED_TABLE(c);
+    if (!c->tracking) return fail(c, G2048_ERR_STATE, "g2048_delta_begin was not called");
+    if (int rc = bind(c)) return rc;
+    USE_TABLE(c);
+    k_delta_pack_touched<<<2048, WG, 0, c->stream>>>(c->delta, (float*)pack, c->slots);
+    if (int rc = launched(c, "k_delta_pack_touched")) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return G2048_OK;
 }
@@ -2443,6 +2709,128 @@ int g2048_delta_device_ptr(g2048_ctx* c, void** ptr) {
     if (int rc = ensure_delta(c)) return rc;
     *ptr = c->delta;
     return G2048_OK;
+}
+
+// ---- RCCL, bound at run time: the library has no link-time dependency on librccl (a process that already carries one —
+// PyTorch ships its own copy under the same SONAME — gets that one back from dlopen).
+namespace {
+struct Rccl {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string err;
+};
+Rccl* rccl() {
+    static Rccl r;
+    if (r.lib || !r.err.empty()) return &r;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names)
+        if ((r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!r.lib) {
+        r.err = std::string("librccl not found: ") + dlerror();
+        return &r;
+    }
+    r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.lib, "ncclGetUniqueId"));
+    r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.lib, "ncclCommInitRank"));
+    r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.lib, "ncclCommDestroy"));
+    r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(dlsym(r.lib, "ncclAllReduce"));
+    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.lib, "ncclGetErrorString"));
+    if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce || !r.GetErrorString) {
+        r.err = "librccl lacks an expected symbol";
+        r.lib = nullptr;
+    }
+    return &r;
+}
+int rccl_fail(g2048_ctx* c, const char* what, ncclResult_t e) {
+    char buf[512];
+    snprintf(buf, sizeof buf, "%s: %s", what, rccl()->GetErrorString ? rccl()->GetErrorString(e) : "RCCL error");
+    if (c) c->err = buf;
+    return G2048_ERR_COMM;
+}
+}  // namespace
+
+int g2048_comm_unique_id(uint8_t* id) {
+    if (!id) return G2048_ERR_ARG;
+    Rccl* r = rccl();
+    if (!r->lib) return G2048_ERR_COMM;
+    static_assert(sizeof(ncclUniqueId) == G2048_COMM_ID_BYTES, "unique id size");
+    ncclUniqueId u;
+    if (r->GetUniqueId(&u) != ncclSuccess) return G2048_ERR_COMM;
+    memcpy(id, &u, sizeof u);
+    return G2048_OK;
+}
+
+int g2048_comm_init(g2048_ctx* c, int rank, int nranks, const uint8_t* id) {
+    if (!c || !id || nranks < 1 || rank < 0 || rank >= nranks) return c ? fail(c, G2048_ERR_ARG, "bad rank / nranks / id") : G2048_ERR_ARG;
+    NEED_TABLE(c);
+    if (c->parent) return fail(c, G2048_ERR_STATE, "the communicator belongs to the context that owns the table");
+    if (c->comm) return fail(c, G2048_ERR_STATE, "communicator already initialised");
+    if (int rc = bind(c)) return rc;
+    Rccl* r = rccl();
+    if (!r->lib) return fail(c, G2048_ERR_COMM, r->err.c_str());
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof u);
+    ncclComm_t comm = nullptr;
+    ncclResult_t e = r->CommInitRank(&comm, nranks, u, rank);       // collective: every rank calls it with the same id
+    if (e != ncclSuccess) return rccl_fail(c, "ncclCommInitRank", e);
+    c->comm = comm;
+    c->comm_rank = rank;
+    c->comm_ranks = nranks;
+    return G2048_OK;
+}
+
+int g2048_comm_destroy(g2048_ctx* c) {
+    if (!c) return G2048_ERR_ARG;
+    if (!c->comm) return G2048_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    ncclResult_t e = rccl()->CommDestroy((ncclComm_t)c->comm);
+    c->comm = nullptr;
+    c->comm_ranks = 1;
+    return e == ncclSuccess ? G2048_OK : rccl_fail(c, "ncclCommDestroy", e);
+}
+
+// End of an epoch, all on the context's stream and without a host wait: the accumulated delta of every rank is
+// sum-all-reduced over xGMI (ncclAllReduce, fp32, table_slots elements; the per-slot mean rule sends [delta | touched],
+// twice that) and W = W0 + result becomes the next epoch's W0.
+int g2048_allreduce_deltas(g2048_ctx* c) {
+    if (!c) return G2048_ERR_ARG;
+    NEED_TABLE(c);
+    if (!c->comm) return fail(c, G2048_ERR_STATE, "g2048_comm_init was not called");
+    if (!c->tracking) return fail(c, G2048_ERR_STATE, "g2048_delta_begin was not called");
+    if (int rc = bind(c)) return rc;
+    USE_TABLE(c);
+    Rccl* r = rccl();
+    const size_t n = c->slots;
+    if (c->update_rule == 1) {
+        if (int rc = ensure_pack(c, 2 * n)) return rc;
+        k_delta_pack_touched<<<2048, WG, 0, c->stream>>>(c->delta, c->pack, n);
+        ncclResult_t e = r->AllReduce(c->pack, c->pack, 2 * n, ncclFloat32, ncclSum, (ncclComm_t)c->comm, c->stream);
+        if (e != ncclSuccess) return rccl_fail(c, "ncclAllReduce", e);
+        k_delta_add_mean<<<2048, WG, 0, c->stream>>>(c->w, c->w0, c->pack, c->delta, n);
+    } else {
+        if (int rc = ensure_pack(c, n)) return rc;
+        ncclResult_t e = r->AllReduce(c->delta, c->pack, n, ncclFloat32, ncclSum, (ncclComm_t)c->comm, c->stream);
+        if (e != ncclSuccess) return rccl_fail(c, "ncclAllReduce", e);
+        k_delta_add<<<2048, WG, 0, c->stream>>>(c->w, c->w0, c->pack, c->delta, n);
+    }
+    return launched(c, "g2048_allreduce_deltas");
+}
+
+// sum of `count` doubles over the ranks, in place (episode statistics, timing): a tiny second all-reduce
+int g2048_allreduce_f64(g2048_ctx* c, double* host_values, int count, int op_max) {
+    if (!c || !host_values || count < 0 || count > 4096) return c ? fail(c, G2048_ERR_ARG, "bad count") : G2048_ERR_ARG;
+    if (!c->comm) return fail(c, G2048_ERR_STATE, "g2048_comm_init was not called");
+    if (count == 0) return G2048_OK;
+    if (int rc = bind(c)) return rc;
+    if (int rc = ensure_scratch(c, (size_t)count * 8)) return rc;
+    if (int rc = h2d(c, c->scratch, host_values, (size_t)count * 8)) return rc;
+    ncclResult_t e = rccl()->AllReduce(c->scratch, c->scratch, (size_t)count, ncclFloat64, op_max ? ncclMax : ncclSum, (ncclComm_t)c->comm, c->stream);
+    if (e != ncclSuccess) return rccl_fail(c, "ncclAllReduce(f64)", e);
+    return d2h(c, host_values, c->scratch, (size_t)count * 8);
 }
 
 int g2048_stream_handle(g2048_ctx* c, void** s) {

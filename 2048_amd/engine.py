@@ -236,7 +236,7 @@ class Engine:
         st = _lib.Stats()
         self._c(self.lib.g2048_stats_get(self.ctx, ctypes.byref(st)))
         return dict(episodes=st.episodes, moves=st.moves, score_sum=st.score_sum, best_score=st.best_score,
-                    max_tile=list(st.max_tile), overflow16=st.overflow16)
+                    max_tile=list(st.max_tile), overflow16=st.overflow16, nonfinite=st.nonfinite, valid_dirs=st.valid_dirs)
 
     def stats_reset(self):
         self._c(self.lib.g2048_stats_reset(self.ctx))
@@ -266,6 +266,39 @@ class Engine:
     def delta_apply(self, src_ptr=None):
         self._c(self.lib.g2048_delta_apply(self.ctx, ctypes.c_void_p(src_ptr)))
 
+    def delta_pack_touched(self, pack_ptr):
+        """pack fp32[2 * slots] = [delta | 1.0 where this rank moved the slot] (per-slot mean rule across ranks)."""
+        self._c(self.lib.g2048_delta_pack_touched(self.ctx, ctypes.c_void_p(pack_ptr)))
+
+    def delta_apply_mean(self, pack_ptr):
+        """W = W0 + delta_sum / max(1, touched_sum) from the all-reduced pack."""
+        self._c(self.lib.g2048_delta_apply_mean(self.ctx, ctypes.c_void_p(pack_ptr)))
+
+    # native RCCL path (include/g2048.h, multi-GPU)
+    @staticmethod
+    def comm_unique_id():
+        lib = _lib.load()
+        buf = (ctypes.c_uint8 * _lib.COMM_ID_BYTES)()
+        check(lib.g2048_comm_unique_id(buf))
+        return bytes(buf)
+
+    def comm_init(self, rank, nranks, unique_id):
+        assert len(unique_id) == _lib.COMM_ID_BYTES
+        buf = (ctypes.c_uint8 * _lib.COMM_ID_BYTES).from_buffer_copy(unique_id)
+        self._c(self.lib.g2048_comm_init(self.ctx, int(rank), int(nranks), buf))
+
+    def comm_destroy(self):
+        self._c(self.lib.g2048_comm_destroy(self.ctx))
+
+    def allreduce_deltas(self):
+        """End of an epoch on the context's stream: RCCL sum all-reduce of the accumulated delta, W = W0 + result."""
+        self._c(self.lib.g2048_allreduce_deltas(self.ctx))
+
+    def allreduce_f64(self, values, op='sum'):
+        v = np.ascontiguousarray(values, np.float64).copy()
+        self._c(self.lib.g2048_allreduce_f64(self.ctx, _buf(v), v.size, 1 if op == 'max' else 0))
+        return v
+
     def delta_ptr(self):
         p = ctypes.c_void_p()
         self._c(self.lib.g2048_delta_device_ptr(self.ctx, ctypes.byref(p)))
@@ -277,6 +310,12 @@ class Engine:
         n = ctypes.c_uint32(0)
         self._c(self.lib.g2048_debug_owner_plan(self.ctx, _buf(out), 1024, ctypes.byref(n)))
         return out[:n.value]
+
+    def td_steps_kernel_ms(self, alpha, nsteps):
+        """ms per launch of (k_td_play, k_td_update_owner, k_td_update_tail, k_apply_*), HIP events on the context's stream."""
+        out = np.zeros(4, np.float32)
+        self._c(self.lib.g2048_td_steps_kernel_ms(self.ctx, float(alpha), int(nsteps), _buf(out)))
+        return [float(x) for x in out]
 
     def td_steps_profiled(self, alpha, nsteps):
         """(ms per k_td_play launch, ms per k_td_update launch), HIP events on the context's stream."""

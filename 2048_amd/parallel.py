@@ -1,13 +1,21 @@
 """Multi-GPU data parallelism for the TD(0) learner: one process per GPU, episodes sharded by lane range, the
-fp32 weight table replicated, and ONE collective per epoch — a sum all-reduce of the weight deltas over
-RCCL/xGMI (torch.distributed backend "nccl"; "gloo" in the CPU tests).  The reference has no counterpart
-(single Python thread, application.py:611); SURVEY.md §8(e) defines the scheme.
+fp32 weight table replicated, and ONE collective per epoch — a sum all-reduce of the accumulated weight deltas
+over RCCL/xGMI.  The reference has no counterpart (single Python thread, r_learning.py:269-296,
+application.py:611); SURVEY.md §8(e) defines the scheme, include/g2048.h ("multi-GPU") the arithmetic:
 
-    sync = DeltaSync(table, dist); sync.begin()
-    loop: table.td_steps(alpha, E); sync.all_reduce()
+    rule 'sum'  : W = W0 + sum_r D_r
+    rule 'mean' : W = W0 + sum_r D_r / max(1, #{r : D_r != 0})      (per slot: the mean over the ranks that moved it)
 
-`table` is anything with delta_begin() / delta_extract_into(tensor) / delta_apply_from(tensor) / slots / device:
-the Engine on a GPU, or a host stand-in in the gloo tests.
+Two transports, same arithmetic:
+    NativeSync  — g2048_comm_init / g2048_allreduce_deltas: ncclAllReduce on the context's own stream, no host wait;
+    DeltaSync   — host-driven through torch.distributed (backend "nccl" = RCCL, or "gloo" in the CPU tests).
+
+    sync.begin()
+    run_epochs(stepper, sync, alpha, steps, epoch)        # the loop bench.py, QAgent.train_run and the tests share
+
+`stepper` is anything with td_steps(alpha, nsteps): the Engine on a GPU, or a host stand-in in the gloo tests.  A
+table for DeltaSync is anything with delta_begin() / delta_extract_into(t) / delta_apply_from(t) (and, for the mean
+rule, delta_pack_touched_into(t2) / delta_apply_mean_from(t2)) / slots / device.
 """
 import numpy as np
 
@@ -19,6 +27,19 @@ def shard_lanes(total_lanes, rank, world):
     count = base + (1 if rank < extra else 0)
     lane0 = rank * base + min(rank, extra)
     return lane0, count
+
+
+def run_epochs(stepper, sync, alpha, steps, epoch):
+    """`steps` board-steps of every lane, the weight deltas exchanged every `epoch` steps (and after the last,
+    shorter epoch).  sync = None: no exchange (one rank)."""
+    done = 0
+    while done < steps:
+        chunk = min(int(epoch), steps - done) if sync is not None else steps - done
+        stepper.td_steps(alpha, chunk)
+        done += chunk
+        if sync is not None:
+            sync.all_reduce()
+    return done
 
 
 class EngineTable:
@@ -38,23 +59,36 @@ class EngineTable:
     def delta_apply_from(self, tensor):
         self.e.delta_apply(tensor.data_ptr())
 
+    def delta_pack_touched_into(self, tensor2):
+        self.e.delta_pack_touched(tensor2.data_ptr())
+
+    def delta_apply_mean_from(self, tensor2):
+        self.e.delta_apply_mean(tensor2.data_ptr())
+
 
 class DeltaSync:
-    def __init__(self, table, dist, group=None):
+    """Host-driven epoch exchange through torch.distributed."""
+
+    def __init__(self, table, dist, group=None, rule='sum'):
         import torch
+        assert rule in ('sum', 'mean')
         self.torch = torch
         self.table = table if hasattr(table, 'delta_extract_into') else EngineTable(table)
-        self.dist, self.group = dist, group
-        self.buf = torch.zeros(self.table.slots, dtype=torch.float32, device=self.table.device)
+        self.dist, self.group, self.rule = dist, group, rule
+        n = self.table.slots * (2 if rule == 'mean' else 1)
+        self.buf = torch.zeros(n, dtype=torch.float32, device=self.table.device)
         self.reduces = 0
 
     def begin(self):
-        """Snapshot W0 = W: deltas are measured from here."""
+        """Start of the first epoch: W0 = W, accumulated delta = 0."""
         self.table.delta_begin()
 
     def all_reduce(self):
-        """D = W - W0 on every rank; D <- sum over ranks; W = W0 + D; W0 = W (the next epoch starts here)."""
-        self.table.delta_extract_into(self.buf)            # synchronises the engine's stream
+        """End of an epoch (see the module docstring for the arithmetic); the next epoch starts from the result."""
+        if self.rule == 'mean':
+            self.table.delta_pack_touched_into(self.buf)   # synchronises the engine's stream
+        else:
+            self.table.delta_extract_into(self.buf)
         if self.buf.is_cuda and self.dist.get_backend(self.group) == 'gloo':
             host = self.buf.cpu()                          # rehearsal on a box without RCCL peers: stage through the host
             self.dist.all_reduce(host, op=self.dist.ReduceOp.SUM, group=self.group)
@@ -63,8 +97,43 @@ class DeltaSync:
             self.dist.all_reduce(self.buf, op=self.dist.ReduceOp.SUM, group=self.group)
         if self.buf.is_cuda:
             self.torch.cuda.synchronize(self.buf.device)
-        self.table.delta_apply_from(self.buf)
+        if self.rule == 'mean':
+            self.table.delta_apply_mean_from(self.buf)
+        else:
+            self.table.delta_apply_from(self.buf)
         self.reduces += 1
+
+
+class NativeSync:
+    """The C ABI's own RCCL path: g2048_comm_init once (collective), then g2048_allreduce_deltas per epoch, queued on
+    the engine's stream.  `exchange_id(id_or_None) -> id` carries rank 0's 128-byte unique id to every rank (any
+    out-of-band channel: torch.distributed broadcast, a TCPStore, a file)."""
+
+    def __init__(self, engine, rank, world, exchange_id):
+        uid = engine.comm_unique_id() if rank == 0 else None
+        uid = exchange_id(uid)
+        engine.comm_init(rank, world, uid)
+        self.e = engine
+        self.reduces = 0
+
+    def begin(self):
+        self.e.delta_begin()
+
+    def all_reduce(self):
+        self.e.allreduce_deltas()                          # the update rule is the context's (g2048_set_update_rule)
+        self.reduces += 1
+
+    def close(self):
+        self.e.comm_destroy()
+
+
+def broadcast_id_torch(dist, group=None):
+    """exchange_id for NativeSync over an initialised torch.distributed group (any backend)."""
+    def exchange(uid):
+        box = [uid]
+        dist.broadcast_object_list(box, src=0, group=group)
+        return box[0]
+    return exchange
 
 
 def reduce_stats(stats, dist, device='cpu', group=None):
@@ -80,3 +149,17 @@ def reduce_stats(stats, dist, device='cpu', group=None):
     out['max_tile'] = [int(v) for v in vec[len(keys):]]
     out['best_score'] = int(best.item())
     return out
+
+
+def combine_deltas(w0, deltas, rule='sum', wire=None):
+    """The epoch arithmetic on host arrays (float64): what every replica holds after the exchange.  Used by the tests
+    as the statement of the cross-rank rule.  wire=np.float32 rounds the summed delta as the fp32 all-reduce does
+    (exact for two ranks: the float64 sum of two fp32 numbers is exact, so one rounding remains)."""
+    d = np.stack([np.asarray(x, np.float64) for x in deltas])
+    total = d.sum(axis=0)
+    if wire is not None:
+        total = total.astype(wire).astype(np.float64)
+    if rule == 'sum':
+        return np.asarray(w0, np.float64) + total
+    touched = (d != 0).sum(axis=0)
+    return np.asarray(w0, np.float64) + total / np.maximum(1, touched)

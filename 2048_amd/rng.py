@@ -114,3 +114,17 @@ def spawn_draw_np(u, n_empty):
 def pick_draw_np(u, n_valid):
     hi = (u >> np.uint64(32)).astype(np.uint64)
     return ((hi * n_valid.astype(np.uint64)) >> np.uint64(32)).astype(np.uint8)
+
+
+# ---------------------------------------------------------------- weight initialisation (g2048_weights_init)
+
+def init_weights_np(count, seed, scale=0.01, first=0):
+    """The table k_weights_init builds — init_weights (r_learning.py:136-149) is U[0, 0.01) per slot; here slot i gets
+    float32(top 24 bits of splitmix64 output of state seed + i) * 2^-24 * scale, counter-based so that every rank
+    builds the same table.  Returns float32[count] for slots first .. first + count - 1."""
+    with np.errstate(over='ignore'):
+        x = np.uint64(seed & MASK64) + np.arange(first, first + count, dtype=np.uint64) + np.uint64(GOLDEN)
+        z = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return (z >> np.uint64(40)).astype(np.float32) * np.float32(2.0 ** -24) * np.float32(scale)

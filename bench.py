@@ -1,18 +1,30 @@
 #!/usr/bin/env python3
 """bench.py — board-steps/sec of the batched TD(0) hot path on N MI355X GPUs.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: one rank per GPU.  Under a launcher (torch.distributed.run sets RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*)
+this process IS a rank; without one it starts N rank processes itself before anything touches a GPU and relays
+rank 0's line.
 
 Workload (BASELINE.json config 4, the configuration the metric is quoted on): the full TD(0) loop of
-QAgent.episode — 4-direction move, n=5 tuple gather + greedy select, TD target, 8-symmetry scatter-add, spawn,
-terminal check / auto-reset — on 2^20 concurrent episodes PER GPU (weak scaling: lanes are sharded by rank, no
-data-path collective; every --epoch steps the fp32 weight deltas are sum-all-reduced with RCCL).
-A "step" is one board-step of every lane.  Prints ONE JSON line on rank 0.
+QAgent.episode (r_learning.py:228-249) — 4-direction move, n=5 tuple gather + greedy select, TD target, 8-symmetry
+scatter-add, spawn, terminal check / auto-reset — on 2^20 concurrent episodes PER GPU (weak scaling: lanes are
+sharded by rank, no data-path collective; every --epoch steps the accumulated fp32 weight deltas are sum-all-reduced
+with RCCL).  A "step" is one board-step of every lane.
+
+Protocol: fresh games are first advanced --condition steps (untimed, reported, independent of
+--warmup) so that the tile distribution is mid-game-like; then W untimed warm-up steps; then --repeats timed regions of
+exactly K steps each, every one bracketed by barrier + device synchronisation, time = MAX over ranks; `value` and
+`ms_per_step` are the MEDIAN region.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import importlib
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -27,7 +39,7 @@ NUM_FEAT = {2: 24, 3: 52, 4: 17, 5: 21, 6: 33}
 
 def algorithmic_bytes(n):
     """Per board-step, SURVEY.md §8(d): env 72 + gathers 4*F*4 + scatter 8*F*(4R+4W) + carry 2*20.
-    Split by kernel: k_td_play = env + gathers + carry write; k_td_update = scatter + carry read."""
+    Split by kernel: k_td_play = env + gathers + carry write; the update kernels = scatter + carry read."""
     F = NUM_FEAT[n]
     play = 72 + 4 * F * 4 + 20
     update = 8 * F * 8 + 20
@@ -115,13 +127,26 @@ def side_workload(pkg, args):
     eng.close()
 
 
-def gather_floor_ms(n, B, device):
-    """Time for the table gathers of one k_td_play launch at one lane per cycle per CU (the measured rate of divergent
-    4-byte loads through the texture addresser)."""
-    import torch
-    p = torch.cuda.get_device_properties(device)
-    clock_hz = getattr(p, 'clock_rate', 2400000) * 1e3
-    return 4.0 * NUM_FEAT[n] * B / (p.multi_processor_count * clock_hz) * 1e3
+def self_launch(args):
+    """--gpus N without a launcher: start the N rank processes (fresh interpreters, so no GPU state is inherited — this
+    parent never imports torch or the HIP library), relay rank 0's stdout, fail if any rank fails."""
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    bad = [c for c in codes if c != 0]
+    if bad:
+        raise SystemExit(f'rank exit codes {codes}')
 
 
 def main():
@@ -129,29 +154,39 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=64)
+    ap.add_argument('--repeats', type=int, default=3, help='timed regions of --steps steps each; the median is reported')
+    ap.add_argument('--condition', type=int, default=64,
+                    help='untimed TD steps that age the fresh boards before --warmup (SURVEY.md 8d input conditioning)')
     ap.add_argument('--batch', type=int, default=1 << 20, help='lanes per GPU')
     ap.add_argument('--n-tuple', type=int, default=5)
     ap.add_argument('--alpha', type=float, default=0.25, help='reference alpha; scaled by the batch rule below')
     ap.add_argument('--epoch', type=int, default=50, help='steps between weight-delta all-reduces (N > 1)')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-mean-line', action='store_true', help='skip the secondary measurement of the per-slot mean rule')
     ap.add_argument('--workload', default='td', choices=['td', 'env', 'eval'],
                     help='td = BASELINE config 4 (the metric); env = config 2 (65 536 lanes, env step only); eval = config 3 '
                          '(262 144 lanes, n=3 evaluate + greedy select); env/eval print a reduced JSON line')
     ap.add_argument('--rule', default='sum', choices=['sum', 'mean'],
                     help="how a step's records are applied: 'sum' = the reference's arithmetic (the metric); 'mean' = per-slot "
-                         "mean (what QAgent uses for batched training; a second accumulation pass)")
+                         "mean (what QAgent uses for batched training)")
     ap.add_argument('--sync-at-one', action='store_true',
-                    help='with one rank, still create the process group and run the per-epoch delta all-reduce (exercises the RCCL path on a 1-GPU box)')
-    ap.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse on one GPU)')
+                    help='with one rank, still build the communicator and run the per-epoch delta all-reduce (exercises the RCCL path on a 1-GPU box)')
+    ap.add_argument('--comm', default='native', choices=['native', 'torch'],
+                    help='delta all-reduce: native = g2048_allreduce_deltas (RCCL on the engine stream; falls back to torch if it '
+                         'cannot be set up), torch = torch.distributed all_reduce')
+    ap.add_argument('--backend', default='nccl', help='torch.distributed backend for control traffic (nccl = RCCL; gloo to rehearse on one GPU)')
     args = ap.parse_args()
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        return self_launch(args)
 
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     n, B, K, W = args.n_tuple, args.batch, args.steps, args.warmup
     if world != args.gpus:
-        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}')
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
 
     dist = None
     if world > 1 or args.sync_at_one:
@@ -184,16 +219,30 @@ def main():
     if args.rule == 'mean':
         eng.set_update_rule(1)
         alpha = args.alpha
-    sync = par.DeltaSync(eng, dist) if dist else None
+
+    sync, comm_kind = None, None
+    if dist:
+        if args.comm == 'native':
+            ok = 1
+            try:
+                sync = par.NativeSync(eng, rank, world, par.broadcast_id_torch(dist))
+                comm_kind = 'native g2048_allreduce_deltas (ncclAllReduce on the engine stream)'
+            except Exception as e:          # e.g. librccl absent: every rank must agree before falling back
+                print(f'[bench] rank {rank}: native RCCL path unavailable ({e!r})', file=sys.stderr)
+                ok = 0
+            import torch
+            flag = torch.tensor([ok], dtype=torch.int32, device='cuda' if args.backend == 'nccl' else 'cpu')
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                if sync is not None:
+                    sync.close()
+                sync = None
+        if sync is None:
+            sync = par.DeltaSync(eng, dist, rule=args.rule)
+            comm_kind = f'torch.distributed all_reduce ({args.backend})'
 
     def run(steps):
-        done = 0
-        while done < steps:
-            chunk = min(args.epoch, steps - done) if sync else steps - done
-            eng.td_steps(alpha, chunk)
-            done += chunk
-            if sync:
-                sync.all_reduce()
+        par.run_epochs(eng, sync, alpha, steps, args.epoch)
 
     def barrier():
         eng.sync()
@@ -202,36 +251,83 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    def max_over_ranks(x):
+        if not dist:
+            return x
+        import torch
+        t = torch.tensor([x], dtype=torch.float64, device='cuda' if args.backend == 'nccl' else 'cpu')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     if sync:
         sync.begin()
+    run(args.condition)                                    # input conditioning: untimed, not part of --warmup
     run(W)
-    barrier()
-    t0 = time.perf_counter()
-    eng.timer_start()
-    run(K)
-    ev_ms = eng.timer_stop()
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist:
-        import torch
-        t = torch.tensor([dt], dtype=torch.float64, device='cuda' if args.backend == 'nccl' else 'cpu')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
-    # per-kernel launch durations (HIP events on the context's stream), after the timed region
-    ms_play, ms_update = eng.td_steps_profiled(alpha, 20)
+    times, ev_times = [], []
+    for _ in range(max(1, args.repeats)):
+        barrier()
+        t0 = time.perf_counter()
+        eng.timer_start()
+        run(K)
+        ev_ms = eng.timer_stop()
+        barrier()
+        times.append(max_over_ranks(time.perf_counter() - t0))
+        ev_times.append(ev_ms)
+    dt = statistics.median(times)
     st = eng.stats()
+
+    # per-kernel launch durations (HIP events on the context's stream), after the timed regions
+    ms_play, ms_owner, ms_tail, ms_apply = eng.td_steps_kernel_ms(alpha, 20)
     by_play, by_update = algorithmic_bytes(n)
-    # the update is k_td_update_owner (+ k_apply_orbits, ~1 % of it; + k_td_update_tail for n = 6), timed together
-    dominant = 'k_td_update' if ms_update >= ms_play else 'k_td_play'
-    dom_ms = max(ms_update, ms_play)
-    dom_bytes = (by_update if dominant == 'k_td_update' else by_play) * B
-    achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
-    traffic = None
+    kernels = {f'k_td_play<{n}>': ms_play, f'k_td_update_owner<{n}>': ms_owner, 'k_apply_orbits': ms_apply}
+    if n == 6:
+        kernels['k_td_update_tail<6>'] = ms_tail
+    dominant = max(kernels, key=kernels.get)
+    traffic_all = {}
     tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
     if os.path.exists(tpath):
         with open(tpath) as f:
-            traffic = json.load(f).get(f'{dominant}_n{n}_b{B}')
+            traffic_all = json.load(f)
+    # `achieved`: algorithmic bytes of the dominant kernel's launch over its measured duration.  Only k_td_play moves
+    # its algorithmic bytes one for one; the update kernels remove most of theirs (orbit and coset reductions, LDS
+    # accumulation), so when one of them is the longest kernel the whole step is quoted instead — a fraction is never
+    # computed from bytes a kernel does not move.
+    ms_step = dt / K * 1e3
+    if dominant.startswith('k_td_play'):
+        r_kernel, r_bytes, r_ms = dominant, by_play * B, ms_play
+    else:
+        r_kernel, r_bytes, r_ms = f'whole step (longest kernel: {dominant})', (by_play + by_update) * B, ms_step
+    achieved = r_bytes / (r_ms * 1e-3) / 1e9
+    roofline = {'bound': 'hbm', 'kernel': r_kernel, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic_all.get(f'{dominant}_b{B}'),
+                'algorithmic_bytes_per_launch': r_bytes, 'ms_per_launch': r_ms,
+                'ms_kernels': kernels,
+                'k_td_play': {'algorithmic_bytes_per_launch': by_play * B, 'ms': ms_play,
+                              'GBps': by_play * B / (ms_play * 1e-3) / 1e9, 'frac': by_play * B / (ms_play * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              # its own bound is not HBM: 4 x num_feat divergent 4-byte gathers per lane, one cache line per
+                              # cycle through each CU's address path
+                              'limited_by': 'L1 address path (distinct cache lines per wave instruction)'},
+                'whole_step': {'algorithmic_bytes': (by_play + by_update) * B, 'ms': ms_step,
+                               'GBps': (by_play + by_update) * B / (ms_step * 1e-3) / 1e9,
+                               'frac': (by_play + by_update) * B / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                'measured_copy_GBps': copy_gbps}
+    if roofline['frac'] > 1.0 or roofline['k_td_play']['frac'] > 1.0:      # cannot happen for bytes a kernel really moves
+        roofline['invalid'] = 'fraction above 1: bookkeeping error'
+
+    mean_line = None
+    if world == 1 and not dist and args.rule == 'sum' and not args.no_mean_line:
+        # the rule the product trains with (QAgent(batch > 1) -> g2048_set_update_rule(1)), same lanes, alpha unscaled
+        eng.set_update_rule(1)
+        eng.td_steps(args.alpha, W)
+        eng.sync()
+        mt = []
+        for _ in range(max(1, args.repeats)):
+            eng.timer_start()
+            eng.td_steps(args.alpha, K)
+            mt.append(eng.timer_stop())
+        mm = statistics.median(mt)
+        mean_line = {'update_rule': 'mean', 'value': B * K / (mm * 1e-3), 'unit': 'board-steps/s', 'ms_per_step': mm / K,
+                     'alpha': args.alpha}
 
     if rank == 0:
         out = {
@@ -239,29 +335,28 @@ def main():
             'value': world * B * K / dt,
             'unit': 'board-steps/s',
             'n_gpus': world, 'steps': K, 'warmup': W,
-            'ms_per_step': dt / K * 1e3,
+            'ms_per_step': ms_step,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'u8 boards / int32 scores / f32 weights', 'data': 'synthetic',
             'config': {'workload': f'BASELINE config 4: full TD(0) loop, {n}-tuple table ({eng.slots * 4} B), '
                                    f'{B} concurrent episodes per GPU, auto-reset',
                        'batch_per_gpu': B, 'n_tuple': n, 'alpha_effective': alpha, 'update_rule': args.rule,
-                       'parallelism': f'episodes sharded over {world} GPU(s)' + (f', weight-delta all-reduce every {args.epoch} steps' if sync else '')},
-            'roofline': {'bound': 'hbm', 'kernel': 'k_td_update_owner' if dominant == 'k_td_update' else dominant, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                         'algorithmic_bytes_per_launch': dom_bytes, 'ms_per_launch': dom_ms,
-                         'ms_k_td_play': ms_play, 'ms_k_td_update': ms_update,
-                         'whole_step_algorithmic_GBps': (by_play + by_update) * B / (dt / K) / 1e9,
-                         # k_td_play's own bound is not HBM: 4 x num_feat divergent 4-byte gathers per lane pass the CU's address
-                         # unit at ~1 lane per cycle; this is that floor for one launch
-                         'ms_k_td_play_gather_floor': gather_floor_ms(n, B, local_rank),
-                         'measured_copy_GBps': copy_gbps},
-            'hip_event_ms_per_step': ev_ms / K,
+                       'parallelism': f'episodes sharded over {world} GPU(s)' + (f', weight-delta all-reduce every {args.epoch} steps via {comm_kind}' if sync else '')},
+            'protocol': {'conditioning_steps': args.condition, 'repeats': len(times), 'statistic': 'median',
+                         'ms_per_step_repeats': [t / K * 1e3 for t in times],
+                         'hip_event_ms_per_step_repeats': [t / K for t in ev_times]},
+            'roofline': roofline,
+            'mean_valid_directions': st['valid_dirs'] / max(1, st['moves']),
             'episodes_finished': st['episodes'],
             'mean_score': st['score_sum'] / max(1, st['episodes']),
         }
+        if mean_line:
+            out['mean_rule'] = mean_line
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(n, args.cpu_seconds)
         print(json.dumps(out), flush=True)
+    if isinstance(sync, par.NativeSync):
+        sync.close()
     eng.close()
     if dist:
         dist.destroy_process_group()

@@ -13,6 +13,14 @@
  *   - directions: 0 left, 1 up, 2 right, 3 down (Game.actions, game_logic.py:50);
  *   - a context owns all device memory and one HIP stream; it is not re-entrant (the caller serialises calls
  *     on one context); distinct contexts are independent.  ctypes releases the GIL around every call.
+ *   - ASYNCHRONY: calls that only launch device work (g2048_reset, g2048_step_random, g2048_weights_init,
+ *     g2048_td_steps, g2048_stats_reset, g2048_clear_carry, g2048_allreduce_deltas ...) return once the work is queued on
+ *     the context's stream; calls that move data to or from host buffers wait for the stream first, and g2048_sync waits
+ *     explicitly.  Errors of queued kernels surface at the next synchronising call.
+ *   - SINGLE WRITER: contexts made with g2048_create_shared run on their own streams over ONE weight table.  The
+ *     library orders their device work by the order of the CALLS (each table-using call first makes its stream wait
+ *     for the latest table-using call of any sibling), so the caller must issue calls on contexts that share a table
+ *     from one thread at a time, and two such contexts never step concurrently.
  *   - there is NO CPU implementation behind this ABI: g2048_create fails with G2048_ERR_NODEV without a GPU.
  */
 #ifndef G2048_H
@@ -24,7 +32,7 @@
 extern "C" {
 #endif
 
-#define G2048_ABI_VERSION 1
+#define G2048_ABI_VERSION 2
 
 enum {
     G2048_OK = 0,
@@ -32,7 +40,8 @@ enum {
     G2048_ERR_HIP = -2,    /* a HIP runtime call failed; see g2048_last_error */
     G2048_ERR_NOMEM = -3,  /* device or host allocation failed */
     G2048_ERR_STATE = -4,  /* call not valid in this state (e.g. no weight table: n_tuple == 0) */
-    G2048_ERR_NODEV = -5   /* no usable GPU */
+    G2048_ERR_NODEV = -5,  /* no usable GPU */
+    G2048_ERR_COMM = -6    /* RCCL is missing or a collective failed; see g2048_last_error */
 };
 
 /* lane flag bits (g2048_get_carry) */
@@ -48,6 +57,8 @@ typedef struct g2048_stats {
     uint64_t best_score;     /* best final score                       (top_score, r_learning.py:302) */
     uint64_t max_tile[20];   /* histogram of the largest tile of finished games (reached[], :307-309) */
     uint64_t overflow16;     /* lanes ended because a 15+15 merge left the reference's tile domain    */
+    uint64_t nonfinite;      /* TD records dropped because their dw was inf / NaN (a poisoned table)  */
+    uint64_t valid_dirs;     /* directions that changed the board, summed over the board-steps (`change` true, :233) */
 } g2048_stats;
 
 /* ---- library / geometry (host only) */
@@ -63,7 +74,8 @@ int g2048_feature_layout(int n_tuple, int64_t* offsets, int64_t* sizes); /* per-
 int g2048_create(int device, uint32_t batch, int n_tuple, uint64_t seed, uint64_t lane0, g2048_ctx** out);
 /* A second set of lanes over the SAME weight table as `parent` (same device, same n-tuple): e.g. one lane for
  * QAgent.episode / evaluate next to the big training batch.  The parent must outlive it; the caller serialises
- * calls on contexts that share a table. */
+ * calls on contexts that share a table (SINGLE WRITER above); device work already queued on the table by the parent
+ * is ordered before the child's. */
 int g2048_create_shared(g2048_ctx* parent, uint32_t batch, uint64_t seed, uint64_t lane0, g2048_ctx** out);
 int g2048_destroy(g2048_ctx* ctx);
 const char* g2048_last_error(const g2048_ctx* ctx);
@@ -120,7 +132,9 @@ int g2048_eval_select(g2048_ctx* ctx, float* value /* [B] */, uint8_t* action /*
  * 8 symmetric images (fp32 atomic adds). */
 int g2048_update(g2048_ctx* ctx, const uint8_t* states /* [count][16] */, const float* dw /* [count] */, int64_t count);
 /* nsteps synchronous board-steps of QAgent.episode (r_learning.py:228-249) for every live lane: all lanes
- * choose with the same table, then every (state, dw) record of the step is added.  alpha is used as given. */
+ * choose with the same table, then every (state, dw) record of the step is added.  alpha is used as given.
+ * ASYNCHRONOUS: returns when the steps are queued (for batches >= 2^17 lanes the host stays at most one step ahead of
+ * the device: it reads the update kernel's load statistics back after every step to keep its work plan balanced). */
 int g2048_td_steps(g2048_ctx* ctx, float alpha, uint32_t nsteps);
 /* how the step's records are added to the table: 1 (default) = LDS-owner kernel (workgroups own 128 KiB table
  * slices in LDS, no global atomics for n <= 5), 0 = one global fp32 atomic per slot.  Same sums either way. */
@@ -133,6 +147,9 @@ int g2048_set_update_rule(g2048_ctx* ctx, int rule);
 /* the same, with HIP events around each of the step's two kernels (synchronises every step): average
  * milliseconds per launch of k_td_play and k_td_update, for the roofline line of bench.py */
 int g2048_td_steps_profiled(g2048_ctx* ctx, float alpha, uint32_t nsteps, float* ms_play, float* ms_update);
+/* per kernel: out4 = average ms per launch of {k_td_play, k_td_update_owner (both passes under rule 1), k_td_update_tail
+ * (n = 6), k_apply_*} */
+int g2048_td_steps_kernel_ms(g2048_ctx* ctx, float alpha, uint32_t nsteps, float* out4);
 
 /* Diagnostics of the LDS-owner update (update mode 1): for each workgroup of the current plan six words
  * {orbit variant, chunk, part, nparts, start clock, end clock} of its last launch (clock: 100 MHz constant counter).
@@ -153,15 +170,35 @@ int g2048_log_game(g2048_ctx* ctx, uint32_t lane, uint32_t slot, uint16_t* moves
 int g2048_stats_get(g2048_ctx* ctx, g2048_stats* out);
 int g2048_stats_reset(g2048_ctx* ctx);
 
-/* ---- multi-GPU plumbing.  Episodes are sharded by lane0 (no data-path collective); once per epoch the host
- * sum-all-reduces the fp32 weight delta with RCCL (torch.distributed backend "nccl") over xGMI:
- *   delta_begin (W0 = W) ... E x td_steps ... delta_extract (D = W - W0) -> all_reduce(D) -> delta_apply (W = W0 + D).
- * dst/src are DEVICE pointers to fp32[table_slots] owned by the caller (e.g. a torch tensor), or NULL to use
- * the context's own buffer (g2048_delta_device_ptr).  Both calls synchronise the context's stream. */
+/* ---- multi-GPU (the reference trains in one Python thread, r_learning.py:269-296, application.py:611).
+ * One process and one context per GPU.  Episodes are sharded by lane0 (no data-path collective); the table is replicated.
+ * An epoch is E board-steps; g2048_delta_begin starts the first one (W0 = W) and from then on every add a step makes to
+ * the table is mirrored in an fp32 accumulator D (the delta is accumulated, not recovered as W - W0).  At the end of an
+ * epoch the ranks exchange D with ONE sum all-reduce over xGMI and every replica becomes
+ *     rule 0 (sum):   W = W0 + sum_r D_r
+ *     rule 1 (mean):  W = W0 + sum_r D_r / max(1, #{r : D_r != 0})   per slot — the mean over the ranks that moved the slot
+ *                     (the payload is [D | touched], twice the table)
+ * and W0 = W, D = 0 for the next epoch.
+ *   native path:  g2048_comm_unique_id on rank 0 -> the 128 bytes reach the other ranks out of band -> g2048_comm_init on
+ *                 every rank (collective) -> loop { g2048_td_steps(E); g2048_allreduce_deltas } — RCCL (ncclAllReduce) on the
+ *                 context's stream, no host wait.  librccl is bound at run time (dlopen): G2048_ERR_COMM if it is absent.
+ *   host-driven:  delta_extract -> any all-reduce of the caller (torch.distributed) -> delta_apply; these three synchronise
+ *                 the context's stream.  dst/src are DEVICE pointers to fp32[table_slots] owned by the caller, or NULL for
+ *                 the context's own accumulator (g2048_delta_device_ptr).  Mean rule: delta_pack_touched(pack fp32[2 * slots])
+ *                 -> all-reduce(pack) -> delta_apply_mean(pack). */
+#define G2048_COMM_ID_BYTES 128
+int g2048_comm_unique_id(uint8_t* id /* [G2048_COMM_ID_BYTES] */);
+int g2048_comm_init(g2048_ctx* ctx, int rank, int nranks, const uint8_t* id /* [G2048_COMM_ID_BYTES] */);
+int g2048_comm_destroy(g2048_ctx* ctx);
+int g2048_allreduce_deltas(g2048_ctx* ctx);
+/* sum (op_max = 0) or maximum (1) of `count` host doubles over the ranks, in place: episode statistics, timings */
+int g2048_allreduce_f64(g2048_ctx* ctx, double* values, int count, int op_max);
 int g2048_weights_device_ptr(g2048_ctx* ctx, void** ptr, int64_t* count);
 int g2048_delta_begin(g2048_ctx* ctx);
 int g2048_delta_extract(g2048_ctx* ctx, void* dst);
 int g2048_delta_apply(g2048_ctx* ctx, const void* src);
+int g2048_delta_pack_touched(g2048_ctx* ctx, void* pack /* device fp32[2 * table_slots] */);
+int g2048_delta_apply_mean(g2048_ctx* ctx, const void* pack);
 int g2048_delta_device_ptr(g2048_ctx* ctx, void** ptr);
 int g2048_stream_handle(g2048_ctx* ctx, void** hip_stream);
 
