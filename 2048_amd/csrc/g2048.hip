@@ -1851,14 +1851,22 @@ int replan(g2048_ctx* c) {
     c->plan_pending = false;
     HIP_TRY(c, hipEventSynchronize(c->ev_plan));
     const uint32_t* h = reinterpret_cast<const uint32_t*>(c->h_stat);
-    for (size_t k = 0; k < c->n_chunks; ++k) {
-        const uint32_t fresh = h[k] - c->hits_seen[k];          // cumulative counters, modulo 2^32
-        c->hits_seen[k] = h[k];
+    uint64_t fresh_total = 0;
+    for (size_t k = 0; k < c->n_chunks; ++k) fresh_total += h[k] - c->hits_seen[k];          // cumulative counters, modulo 2^32
+    // steps without records (the first move of fresh games makes none) say nothing about the load: keep what we have
+    const bool informative = fresh_total >= (uint64_t)c->B / 4 * c->steps_since_read;
+    for (size_t k = 0; k < c->n_chunks && informative; ++k) {
+        const uint32_t fresh = h[k] - c->hits_seen[k];
         const double per_step = (double)fresh / c->steps_since_read;
         c->load[k] = c->plan_measured ? 0.5 * c->load[k] + 0.5 * per_step : per_step;
     }
-    c->plan_measured = true;
+    for (size_t k = 0; k < c->n_chunks; ++k) c->hits_seen[k] = h[k];
     c->steps_since_read = 0;
+    if (!informative) {             // (the clocks of an empty launch say nothing either)
+        c->steps_since_plan = 0;
+        return G2048_OK;
+    }
+    c->plan_measured = true;
     // the last launch's workgroup clocks: work of a chunk = (mean duration - fixed part) x its workgroups
     double makespan = 0;
     if (c->plan.size() == c->n_slices && c->n_slices) {

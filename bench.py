@@ -155,7 +155,7 @@ def main():
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=64)
     ap.add_argument('--repeats', type=int, default=3, help='timed regions of --steps steps each; the median is reported')
-    ap.add_argument('--condition', type=int, default=64,
+    ap.add_argument('--condition', type=int, default=256,
                     help='untimed TD steps that age the fresh boards before --warmup (SURVEY.md 8d input conditioning)')
     ap.add_argument('--batch', type=int, default=1 << 20, help='lanes per GPU')
     ap.add_argument('--n-tuple', type=int, default=5)

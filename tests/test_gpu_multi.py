@@ -30,8 +30,8 @@ def test_weights_init_matches_spec(n):
     assert w.min() >= 0.0 and w.max() < 0.01
     assert abs(w.mean() - 0.005) < 2e-5 and abs(w.std() - 0.01 / np.sqrt(12)) < 2e-5
     offs, sizes = pkg.engine.feature_layout(n)              # no feature's table is biased: action 0 gets no head start (:124-126)
-    means = [w[o:o + s].mean() for o, s in zip(offs, sizes)]
-    assert max(abs(m - 0.005) for m in means) < 2e-4
+    for o, s in zip(offs, sizes):                           # within 5 standard errors of the mean of U[0, 0.01)
+        assert abs(w[o:o + s].mean() - 0.005) < 5 * 0.01 / np.sqrt(12.0 * s)
     eng.init_weights(seed=8, scale=0.01)
     assert not np.array_equal(eng.get_weights(), w)
     eng.close()
@@ -66,8 +66,10 @@ def test_accumulated_delta_and_native_allreduce_world1(n, rule):
         eng.delta_extract(d.data_ptr())
         w_mid = eng.get_weights()
         if epoch == 0:
-            if n != 6:                  # (n = 6: the f_6 orbits end as fp32 atomics, whose order is not repeatable)
+            if n <= 4:                  # every sum in 64-bit fixed point: repeatable bit for bit
                 assert np.array_equal(w_mid, ref), 'tracking the delta must not change the steps'
+            else:                       # (the cross orbit sums with fp32 LDS atomics, the f_6 orbits with global ones: order varies)
+                assert np.abs(w_mid.astype(np.float64) - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
             assert np.array_equal(eng.get_boards(), boards_ref)
         acc = d.cpu().numpy().astype(np.float64)
         assert np.abs(acc).max() > 0
