@@ -457,6 +457,124 @@ __device__ __forceinline__ Choice choose(const float* __restrict__ w, const Move
     return c;
 }
 
+// ---- LDS-resident hot set of the table (k_td_play).  The gathers are bound by the CU's L1: a wave instruction touches
+// ~57 separate cache lines, a third of them miss (TCP counters, profiles/), and the address path stalls behind them.
+// Two thirds of a fresh agent's four-cell reads — half of a trained agent's — fall on tuples whose four tiles are all
+// <= 32 (6^4 = 1 296 of a feature's 65 536 entries).  Those 17 x 1 296 entries (88 KB) are copied into LDS once per
+// launch and read from there; the LDS takes divergent lanes about ten times faster than the L1's tag path, and the L1
+// keeps its lines for the cold tail.
+constexpr uint32_t HOT_PER_FEATURE = 1296u, HOT_FEATURES = 17u, HOT_SLOTS = HOT_FEATURES * HOT_PER_FEATURE;
+constexpr int PLAY_HOT_WG = 768;        // one workgroup per CU shares the 88 KB copy (3 waves per SIMD, as before)
+
+// every nibble of the 16-bit index <= 5
+__device__ __forceinline__ bool hot4(uint32_t idx) { return ((idx | (idx + 0x2222u)) & 0x8888u) == 0u; }
+// base-16 digits n0 n1 n2 n3 (all <= 5) -> ((n0 * 6 + n1) * 6 + n2) * 6 + n3
+__device__ __forceinline__ uint32_t compact6(uint32_t idx) {
+    const uint32_t t = idx >> 8, b = idx & 0xFFu;
+    const uint32_t p = t - 10u * (t >> 4), q = b - 10u * (b >> 4);
+    return p * 36u + q;
+}
+__device__ __forceinline__ uint32_t expand6(uint32_t k) {
+    return ((k / 216u) << 12) | (((k / 36u) % 6u) << 8) | (((k / 6u) % 6u) << 4) | (k % 6u);
+}
+
+template <int TPB>
+__device__ __forceinline__ void load_hot_set(float* hot, const float* __restrict__ w) {
+    for (uint32_t j = threadIdx.x; j < HOT_SLOTS; j += TPB) {
+        const uint32_t f = j / HOT_PER_FEATURE, k = j - f * HOT_PER_FEATURE;
+        hot[j] = w[f * 65536u + expand6(k)];
+    }
+    __syncthreads();
+}
+
+// One table entry of a four-cell feature f (slot = f * 65536 + idx): from the LDS copy when the tuple is hot, else from
+// memory — ONE flat load whose lanes point into either aperture, so there is no second result register and no branch.
+__device__ __forceinline__ float ld_quad(const float* __restrict__ w, const float* hot, uint32_t f, uint32_t slot, bool use) {
+    const uint32_t idx = slot & 0xFFFFu;
+    const bool h = hot4(idx);
+    const float* p = h ? hot + (f * HOT_PER_FEATURE + compact6(idx)) : w + slot;
+    p = use ? p : hot;                  // directions that do not change the board read one fixed LDS word
+    return *p;
+}
+
+// choose<N> with the hot set (n >= 4: features 0..16 are the four-cell tuples)
+template <int N>
+__device__ __forceinline__ Choice choose_hot(const float* __restrict__ w, const float* hot, const Moves4& mv) {
+    constexpr int F = Shape<N>::F;
+    static_assert(N >= 4, "the hot set covers the four-cell features");
+    Choice c;
+    c.action = -1;
+    c.value = -INFINITY;
+    int first_valid = -1;
+#define G2048_HOT_DIR(M, X)                                                                 \
+    float X[F];                                                                             \
+    {                                                                                       \
+        uint32_t s[F];                                                                      \
+        feature_slots<N>(pack_board((M).after), s);                                         \
+        _Pragma("unroll") for (int f = 0; f < 17; ++f) X[f] = ld_quad(w, hot, (uint32_t)f, s[f], (M).changed); \
+        _Pragma("unroll") for (int f = 17; f < F; ++f) X[f] = ld_w(w, (M).changed ? s[f] : 0u);                \
+    }
+    if constexpr (F <= G2048_BATCH4_MAXF) {
+        G2048_HOT_DIR(mv.m0, x0)
+        G2048_HOT_DIR(mv.m1, x1)
+        G2048_HOT_DIR(mv.m2, x2)
+        G2048_HOT_DIR(mv.m3, x3)
+        float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f, v3 = 0.0f;      // each a left-to-right sum, as QAgent.evaluate
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            v0 += x0[f];
+            v1 += x1[f];
+            v2 += x2[f];
+            v3 += x3[f];
+        }
+        c.v[0] = mv.m0.changed ? v0 : -INFINITY;
+        c.v[1] = mv.m1.changed ? v1 : -INFINITY;
+        c.v[2] = mv.m2.changed ? v2 : -INFINITY;
+        c.v[3] = mv.m3.changed ? v3 : -INFINITY;
+    } else {
+        {
+            G2048_HOT_DIR(mv.m0, x0)
+            G2048_HOT_DIR(mv.m1, x1)
+            float v0 = 0.0f, v1 = 0.0f;
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+                v0 += x0[f];
+                v1 += x1[f];
+            }
+            c.v[0] = mv.m0.changed ? v0 : -INFINITY;
+            c.v[1] = mv.m1.changed ? v1 : -INFINITY;
+        }
+        {
+            G2048_HOT_DIR(mv.m2, x2)
+            G2048_HOT_DIR(mv.m3, x3)
+            float v2 = 0.0f, v3 = 0.0f;
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+                v2 += x2[f];
+                v3 += x3[f];
+            }
+            c.v[2] = mv.m2.changed ? v2 : -INFINITY;
+            c.v[3] = mv.m3.changed ? v3 : -INFINITY;
+        }
+    }
+#undef G2048_HOT_DIR
+    const bool ch[4] = {mv.m0.changed, mv.m1.changed, mv.m2.changed, mv.m3.changed};
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+        if (ch[d]) {
+            if (first_valid < 0) first_valid = d;
+            if (c.v[d] > c.value) {
+                c.value = c.v[d];
+                c.action = d;
+            }
+        }
+    if (c.action < 0 && first_valid >= 0) {     // every value was -inf or NaN (a poisoned table): still make a legal move
+        c.action = first_valid;
+        c.value = c.v[first_valid];
+    }
+    return c;
+}
+
 template <int N>
 __global__ __launch_bounds__(WG) void k_eval_select(const uint4* boards, uint32_t B, const float* __restrict__ w, float* value,
                                                     uint8_t* action, float4* values4) {
@@ -613,13 +731,16 @@ __device__ __forceinline__ void log_step(const GameLog& lg, uint32_t i, uint32_t
 // Step part 1 — the body of `while not game.game_over` in QAgent.episode (r_learning.py:228-246) for every live
 // lane, all reading the same table.  `prev` is double-buffered: prev_cur holds `state`, prev_nxt receives this
 // step's afterstate, so the main record needs no copy.
-template <int N>
-__global__ __launch_bounds__(WG) void k_td_play(uint4* boards, int32_t* scores, ulonglong2* rng, uint4* prev_nxt, float* label, uint8_t* flags,
-                                                uint32_t B, const float* __restrict__ w, float alpha, TdRecs recs, int auto_reset,
-                                                Stats* stats, uint16_t* last_move, GameLog lg) {
+template <int N, int TPB, bool HOT>
+__global__ __launch_bounds__(TPB) void k_td_play(uint4* boards, int32_t* scores, ulonglong2* rng, uint4* prev_nxt, float* label, uint8_t* flags,
+                                                 uint32_t B, const float* __restrict__ w, float alpha, TdRecs recs, int auto_reset,
+                                                 Stats* stats, uint16_t* last_move, GameLog lg) {
     constexpr float F = (float)Shape<N>::F;
+    constexpr uint32_t WG = TPB;        // (shadows the file-wide 256: lane blocks are as wide as the workgroup)
     __shared__ WgStats ws;
+    __shared__ float hot[HOT ? HOT_SLOTS : 1];
     wg_stats_init(&ws);
+    if constexpr (HOT) load_hot_set<TPB>(hot, w);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         *recs.qcount_next = 0;
         *recs.dwmax_next = 0;
@@ -651,7 +772,11 @@ __global__ __launch_bounds__(WG) void k_td_play(uint4* boards, int32_t* scores, 
             int32_t score = scores[i];
             float old_label = label[i];
             Moves4 mv = all_moves(b);
-            Choice c = choose<N>(w, mv);
+            Choice c;
+            if constexpr (HOT)
+                c = choose_hot<N>(w, hot, mv);
+            else
+                c = choose<N>(w, mv);
             bool over, overflow = false;
             if (c.action >= 0) {
                 Moved ch = pick(mv, (uint32_t)c.action);
@@ -774,6 +899,7 @@ struct Slice {
     uint32_t orb_tlo, orb_dlo, chunk0;
     uint64_t fb_mask;
     uint32_t cshift;        // log2 of the slots per chunk of this orbit table (OWN_SLOTS, or OWN_SLOTS / 2 for the fixed-point orbits)
+    uint32_t fixed;         // 1: this workgroup sums in 64-bit fixed point (own_fixed, or every variant under the one-pass mean rule)
 };
 
 // Symmetry orbits (n >= 4).  QAgent.update adds dw at f_i(g.x) for all 8 images g (r_learning.py:207-214).  Features
@@ -858,12 +984,19 @@ __device__ __forceinline__ long long to_fixed(float dw, double scale) {
 // in 64-bit fixed point: dw * 2^S with S chosen from the step's largest |dw| so that 2^24 adds cannot overflow and a
 // dw 2^-14 times smaller than the largest is still exact; the flush converts back.  Half as many slots fit in LDS
 // (chunks of 16 384), the sums no longer depend on the order of the adds.
+// One-pass mean rule (cbits > 0): the low `cbits` bits of a fixed-point slot count the adds, the rest is the sum — every
+// add is (dw * 2^S << cbits) + 1, the flush splits the word again (k_td_update_owner).  cbits = 0: sums only.
+__device__ __forceinline__ unsigned long long packed_add(float dw, double scale, uint32_t cbits) {
+    const long long fixed = to_fixed(dw, scale);
+    return ((unsigned long long)fixed << cbits) + (cbits ? 1ull : 0ull);
+}
+
 template <int N, int F0, int FC, bool FB, bool FIXED, uint32_t IMAGES>
 __device__ __forceinline__ void own_accum(const Packed& p, float dw, bool valid, float* acc, const Slice& sl, uint32_t& nhit, float* D,
-                                          uint32_t* fb_hits, float scale) {
+                                          float* Dc, uint32_t* fb_hits, float scale, uint32_t cbits) {
     constexpr int F = Shape<N>::F;
-    long long fixed = 0;
-    if (FIXED) fixed = to_fixed(dw, (double)scale);
+    unsigned long long fixed = 0;
+    if (FIXED) fixed = packed_add(dw, (double)scale, cbits);
 #pragma unroll
     for (uint32_t g = 0; g < 8; ++g) {
         if (!((IMAGES >> g) & 1u)) continue;
@@ -875,7 +1008,7 @@ __device__ __forceinline__ void own_accum(const Packed& p, float dw, bool valid,
             const bool hit = valid && local < sl.size;
             if (hit) {
                 if (FIXED)
-                    atomicAdd(reinterpret_cast<unsigned long long*>(acc) + local, (unsigned long long)fixed);
+                    atomicAdd(reinterpret_cast<unsigned long long*>(acc) + local, fixed);
                 else
                     atomicAdd(&acc[local], dw);
             }
@@ -884,6 +1017,7 @@ __device__ __forceinline__ void own_accum(const Packed& p, float dw, bool valid,
                 const uint32_t rel = s[f] - sl.orb_tlo, ch = rel >> sl.cshift;
                 if ((sl.fb_mask >> ch) & 1u) {
                     __hip_atomic_fetch_add(&D[sl.orb_dlo + rel], dw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (Dc) __hip_atomic_fetch_add(&Dc[sl.orb_dlo + rel], 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     atomicAdd(&fb_hits[ch], 1u);            // LDS counter, flushed once per workgroup
                 }
             }
@@ -894,16 +1028,16 @@ __device__ __forceinline__ void own_accum(const Packed& p, float dw, bool valid,
 // the same accumulation from precomputed orbit indices (k_td_play's OrbitIdx records); idx are relative to the orbit table
 template <int NI, bool FB, bool FIXED>
 __device__ __forceinline__ void own_accum_idx(const uint32_t (&idx)[NI], float dw, bool valid, float* acc, const Slice& sl, uint32_t lo_rel,
-                                              uint32_t& nhit_wave, float* D, uint32_t* fb_hits, double scale) {
-    long long fixed = 0;
-    if (FIXED) fixed = to_fixed(dw, scale);
+                                              uint32_t& nhit_wave, float* D, float* Dc, uint32_t* fb_hits, double scale, uint32_t cbits) {
+    unsigned long long fixed = 0;
+    if (FIXED) fixed = packed_add(dw, scale, cbits);
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
         const uint32_t rel = idx[j], local = rel - lo_rel;
         const bool hit = valid && local < sl.size;
         if (hit) {
             if (FIXED)
-                atomicAdd(reinterpret_cast<unsigned long long*>(acc) + local, (unsigned long long)fixed);
+                atomicAdd(reinterpret_cast<unsigned long long*>(acc) + local, fixed);
             else
                 atomicAdd(&acc[local], dw);
         }
@@ -912,17 +1046,17 @@ __device__ __forceinline__ void own_accum_idx(const uint32_t (&idx)[NI], float d
             const uint32_t ch = rel >> sl.cshift;
             if ((sl.fb_mask >> ch) & 1u) {
                 __hip_atomic_fetch_add(&D[sl.orb_dlo + rel], dw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (Dc) __hip_atomic_fetch_add(&Dc[sl.orb_dlo + rel], 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 atomicAdd(&fb_hits[ch], 1u);            // LDS counter, flushed once per workgroup
             }
         }
     }
 }
 
-template <int N, int V, bool FB>
-__device__ __forceinline__ void own_run(float* acc, const Slice& s, const TdRecs& recs, uint32_t B, uint32_t* hits, float* D, uint32_t* fb_hits,
-                                        float scale) {
+template <int N, int V, bool FB, bool FIXED>
+__device__ __forceinline__ void own_run(float* acc, const Slice& s, const TdRecs& recs, uint32_t B, uint32_t* hits, float* D, float* Dc,
+                                        uint32_t* fb_hits, float scale, uint32_t cbits) {
     constexpr int F0 = OwnVariants<N>::f0(V), FC = OwnVariants<N>::fc(V), OWN_UNROLL = OwnUnroll<FC>::U;
-    constexpr bool FIXED = own_fixed(N, V);
     constexpr uint32_t IMAGES = N >= 4 ? COSET_MASK[V < 6 ? V : 0] : 0xFFu;
     uint32_t nhit = 0, nhit_wave = 0;
     if constexpr (N >= 4) {
@@ -954,7 +1088,7 @@ __device__ __forceinline__ void own_run(float* acc, const Slice& s, const TdRecs
             }
 #pragma unroll
             for (int u = 0; u < U; ++u)
-                own_accum_idx<NI, FB, FIXED>(idx[u], dw[u], dw[u] != 0.0f, acc, s, lo_rel, nhit_wave, D, fb_hits, (double)scale);
+                own_accum_idx<NI, FB, FIXED>(idx[u], dw[u], dw[u] != 0.0f, acc, s, lo_rel, nhit_wave, D, Dc, fb_hits, (double)scale, cbits);
         }
     } else {   // main records: this part's share of the lanes, OWN_UNROLL records per thread in flight; the loop bounds are
         // wave-uniform
@@ -972,7 +1106,8 @@ __device__ __forceinline__ void own_run(float* acc, const Slice& s, const TdRecs
                 if (recs.unit) dw[u] = dw[u] != 0.0f ? 1.0f : 0.0f;
             }
 #pragma unroll
-            for (int u = 0; u < OWN_UNROLL; ++u) own_accum<N, F0, FC, FB, FIXED, IMAGES>(unpack4(st[u]), dw[u], dw[u] != 0.0f, acc, s, nhit, D, fb_hits, scale);
+            for (int u = 0; u < OWN_UNROLL; ++u)
+                own_accum<N, F0, FC, FB, FIXED, IMAGES>(unpack4(st[u]), dw[u], dw[u] != 0.0f, acc, s, nhit, D, Dc, fb_hits, scale, cbits);
         }
     }
     {   // terminal queue
@@ -982,7 +1117,8 @@ __device__ __forceinline__ void own_run(float* acc, const Slice& s, const TdRecs
             const uint32_t r = base0 + threadIdx.x;
             const bool ok = r < end;
             const uint32_t rr = ok ? r : end - 1;
-            own_accum<N, F0, FC, FB, FIXED, IMAGES>(ld_packed(recs.qstate, rr), recs.unit ? 1.0f : recs.qdw[rr], ok, acc, s, nhit, D, fb_hits, scale);
+            own_accum<N, F0, FC, FB, FIXED, IMAGES>(ld_packed(recs.qstate, rr), recs.unit ? 1.0f : recs.qdw[rr], ok, acc, s, nhit, D, Dc, fb_hits, scale,
+                                                    cbits);
         }
     }
     // load statistics for the planner: one counter bump per wave
@@ -993,40 +1129,54 @@ __device__ __forceinline__ void own_run(float* acc, const Slice& s, const TdRecs
 }
 
 template <int N, int V>
-__device__ __forceinline__ void own_dispatch(float* acc, const Slice& s, const TdRecs& recs, uint32_t B, uint32_t* hits, float* D,
-                                             uint32_t* fb_hits, float scale) {
+__device__ __forceinline__ void own_dispatch(float* acc, const Slice& s, const TdRecs& recs, uint32_t B, uint32_t* hits, float* D, float* Dc,
+                                             uint32_t* fb_hits, float scale, uint32_t cbits) {
     if constexpr (V < OwnVariants<N>::COUNT) {
         if (s.variant == (uint32_t)V) {
             // the fallback duty (global atomics for chunks nobody holds in LDS) is carried by few workgroups: two
-            // instantiations keep its tests out of everybody else's inner loop
-            if (N >= 4 && s.fb_mask)
-                own_run<N, V, true>(acc, s, recs, B, hits, D, fb_hits, scale);
-            else
-                own_run<N, V, false>(acc, s, recs, B, hits, D, fb_hits, scale);
+            // instantiations keep its tests out of everybody else's inner loop.  A variant that own_fixed leaves in fp32
+            // (the cross orbit) also exists in fixed point: the one-pass mean rule needs the packed counts.
+            const bool fb = N >= 4 && s.fb_mask;
+            if (own_fixed(N, V) || s.fixed) {
+                if (fb)
+                    own_run<N, V, true, true>(acc, s, recs, B, hits, D, Dc, fb_hits, scale, cbits);
+                else
+                    own_run<N, V, false, true>(acc, s, recs, B, hits, D, Dc, fb_hits, scale, cbits);
+            } else if constexpr (!own_fixed(N, V)) {
+                if (fb)
+                    own_run<N, V, true, false>(acc, s, recs, B, hits, D, Dc, fb_hits, scale, cbits);
+                else
+                    own_run<N, V, false, false>(acc, s, recs, B, hits, D, Dc, fb_hits, scale, cbits);
+            }
         } else
-            own_dispatch<N, V + 1>(acc, s, recs, B, hits, D, fb_hits, scale);
+            own_dispatch<N, V + 1>(acc, s, recs, B, hits, D, Dc, fb_hits, scale, cbits);
     }
 }
 
-// `dst` is the orbit table D (n >= 4) or the weight table itself (n = 2, 3)
+// `dst` is the orbit table D (n >= 4) or the weight table itself (n = 2, 3).  `cdst` (null unless the per-slot mean rule runs
+// in one pass): where the add counts go — the accumulation then packs count and sum into one 64-bit LDS word.
 template <int N>
-__global__ __launch_bounds__(OWN_WG) void k_td_update_owner(float* dst, TdRecs recs, uint32_t B, const Slice* slices, uint32_t* hits,
+__global__ __launch_bounds__(OWN_WG) void k_td_update_owner(float* dst, float* cdst, TdRecs recs, uint32_t B, const Slice* slices, uint32_t* hits,
                                                             uint64_t* wg_clock) {
     __shared__ float acc[OWN_SLOTS];
     __shared__ uint32_t fb_hits[64];
     const Slice s = slices[blockIdx.x];
     if (threadIdx.x == 0) wg_clock[2 * blockIdx.x] = wall_clock64();    // feeds the planner; g2048_debug_owner_plan shows them
-    const bool fixed = own_fixed(N, (int)s.variant);
-    // fixed-point scale 2^S from the step's largest |dw| (< 2^e): 2^24 adds of at most 2^(e+S) stay below 2^62
+    const bool fixed = own_fixed(N, (int)s.variant) || s.fixed;
+    // fixed-point scale 2^S from the step's largest |dw| (< 2^e): a slot can take every visited image of every record
+    // of this part (2^add_bits adds), and |sum| < 2^(add_bits + e + S) must fit the sum field (61 bits, or what the count
+    // bits leave of them)
     float scale = 1.0f, inv_scale = 1.0f;
+    uint32_t cbits = 0;
     if (fixed) {
         const float big = recs.unit ? 1.0f : __uint_as_float(*recs.dwmax);
         int e = big > 0.0f ? ilogbf(big) + 1 : 0;
-        // a slot can take all 4 visited images of every record of this part: |sum| < 4 x records x 2^(e+S) must stay below 2^61
         const uint32_t part_recs = (B + s.nparts - 1) / s.nparts + *recs.qcount;
-        const int add_bits = 32 - __clz((int)(part_recs < (1u << 29) ? 4u * part_recs : 0x7FFFFFFFu));
+        const uint32_t per_rec = N >= 4 ? 4u : 8u;          // adds one record can make to one slot
+        const int add_bits = 32 - __clz((int)(part_recs < (1u << 28) ? per_rec * part_recs : 0x7FFFFFFFu));
+        if (cdst) cbits = (uint32_t)add_bits + 1u;
         int S = 38 - e;
-        if (S > 61 - e - add_bits) S = 61 - e - add_bits;
+        if (S > 61 - (int)cbits - e - add_bits) S = 61 - (int)cbits - e - add_bits;
         S = S > 100 ? 100 : (S < -60 ? -60 : S);
         scale = ldexpf(1.0f, S);
         inv_scale = ldexpf(1.0f, -S);
@@ -1035,20 +1185,26 @@ __global__ __launch_bounds__(OWN_WG) void k_td_update_owner(float* dst, TdRecs r
     for (uint32_t j = threadIdx.x; j < words; j += OWN_WG) acc[j] = 0.0f;
     if (threadIdx.x < 64) fb_hits[threadIdx.x] = 0;
     __syncthreads();
-    own_dispatch<N, 0>(acc, s, recs, B, hits, dst, fb_hits, scale);
+    own_dispatch<N, 0>(acc, s, recs, B, hits, dst, cdst, fb_hits, scale, cbits);
     __syncthreads();
     if (threadIdx.x < 64 && fb_hits[threadIdx.x]) atomicAdd(&hits[s.chunk0 + threadIdx.x], fb_hits[threadIdx.x]);
+    const unsigned long long cmask = (1ull << cbits) - 1ull;
     for (uint32_t j = threadIdx.x; j < s.size; j += OWN_WG) {
-        float v;
-        if (fixed)
-            v = (float)((double)(long long)reinterpret_cast<const unsigned long long*>(acc)[j] * (double)inv_scale);
-        else
+        float v, cnt = 0.0f;
+        if (fixed) {
+            const unsigned long long word = reinterpret_cast<const unsigned long long*>(acc)[j];
+            const unsigned long long n = word & cmask;                         // (0 without count bits)
+            v = (float)((double)((long long)(word - n) >> cbits) * (double)inv_scale);
+            cnt = (float)n;
+        } else {
             v = acc[j];
-        if (v != 0.0f) {
-            if (s.nparts == 1)
-                dst[s.dlo + j] += v;                               // this workgroup is the only writer of the slice
-            else
-                __hip_atomic_fetch_add(&dst[s.dlo + j], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (s.nparts == 1) {                                   // this workgroup is the only writer of the slice
+            if (v != 0.0f) dst[s.dlo + j] += v;
+            if (cnt != 0.0f) cdst[s.dlo + j] += cnt;
+        } else {
+            if (v != 0.0f) __hip_atomic_fetch_add(&dst[s.dlo + j], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (cnt != 0.0f) __hip_atomic_fetch_add(&cdst[s.dlo + j], cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     if (threadIdx.x == 0) wg_clock[2 * blockIdx.x + 1] = wall_clock64();
@@ -1345,6 +1501,9 @@ struct g2048_ctx {
         double add_cost = 3.0, thr = 0.01, fixed_ratio = 0.25;
         int plan_feedback = 1, plan_xcd = 1, debug_plan = 0;
         unsigned play_wgs = 0;
+        int mean_one_pass = 1;          // per-slot mean rule: counts packed beside the sums (0: always two accumulation passes)
+        int play_hot = 0;               // 1: k_td_play reads the hot four-cell tuples from an LDS copy (n >= 4, big batches); measured, not faster
+        uint32_t play_hot_min = 1u << 16;   // smallest batch that takes that path (a workgroup copies 88 KB per launch)
     } knob;
     std::vector<double> load;           // smoothed adds per step per chunk
     std::vector<double> work;           // measured workgroup time x workgroups per chunk (clock ticks; 0 = not measured yet)
@@ -1431,6 +1590,9 @@ void read_knobs(g2048_ctx* c) {
     if (const char* e = getenv("G2048_PLAN_XCD")) k.plan_xcd = atoi(e);
     if (getenv("G2048_DEBUG_PLAN")) k.debug_plan = 1;
     if (const char* e = getenv("G2048_PLAY_WGS")) k.play_wgs = (unsigned)atoi(e);
+    if (const char* e = getenv("G2048_PLAY_HOT")) k.play_hot = atoi(e);
+    if (const char* e = getenv("G2048_MEAN_ONE_PASS")) k.mean_one_pass = atoi(e);
+    if (const char* e = getenv("G2048_PLAY_HOT_MIN")) k.play_hot_min = (uint32_t)atoi(e);
 }
 
 int bind(g2048_ctx* c) {
@@ -1646,6 +1808,9 @@ struct ChunkInfo {
     uint32_t orb_tlo, orb_dlo, chunk0, orb_chunks;      // the orbit table this chunk belongs to (n >= 4)
 };
 
+// the per-slot mean rule packs add counts beside the sums, which needs the fixed-point form for every variant
+bool chunk_fixed(const g2048_ctx* c, int variant) { return own_fixed(c->n, variant) || c->update_rule == 1; }
+
 std::vector<ChunkInfo> table_chunks(const g2048_ctx* c) {
     std::vector<ChunkInfo> v;
     if (c->n == 2) {
@@ -1661,7 +1826,7 @@ std::vector<ChunkInfo> table_chunks(const g2048_ctx* c) {
                 if (feature_offset(c->n, j) == oi.off[0]) rep = (uint32_t)j;
             const uint32_t first = (uint32_t)v.size();
             if (o >= 6 || (int)rep != ORBIT_REPS[o]) return {};      // (checked by the caller: empty plan = unexpected orbit structure)
-            const uint32_t csz = own_fixed(c->n, (int)o) ? FIXED_SLOTS : OWN_SLOTS;
+            const uint32_t csz = chunk_fixed(c, (int)o) ? FIXED_SLOTS : OWN_SLOTS;
             for (uint32_t lo = 0; lo < oi.size; lo += csz)
                 v.push_back({o, oi.off[0] + lo, csz, oi.base + lo, oi.digits == 4 ? 1.0 : 2.0, oi.off[0], oi.base, first, oi.size / csz});
         }
@@ -1740,7 +1905,7 @@ int build_slices(g2048_ctx* c) {
     for (size_t k = 0; k < nc; ++k)
         if (in_lds[k]) {
             // an add costs ~12x less where the sums are 64-bit fixed point (ds_add_u64) than where they are fp32 (ds_add_f32)
-            const double per_add = (c->n >= 4 && own_fixed(c->n, (int)chunks[k].variant)) ? add_cost * fixed_ratio : add_cost;
+            const double per_add = (c->n >= 4 && chunk_fixed(c, (int)chunks[k].variant)) ? add_cost * fixed_ratio : add_cost;
             cost[k] = chunks[k].scan * B + per_add * c->load[k];
             total += cost[k];
             ++n_lds;
@@ -1768,7 +1933,8 @@ int build_slices(g2048_ctx* c) {
     std::vector<uint32_t> parts(nc, 0);
     auto slice_of = [&](size_t k, uint32_t p, uint32_t np) {
         return Slice{chunks[k].variant, chunks[k].tlo, chunks[k].size, chunks[k].dlo, p, np, (uint32_t)k,
-                     chunks[k].orb_tlo, chunks[k].orb_dlo, chunks[k].chunk0, duty[k], chunks[k].size >= OWN_SLOTS ? 15u : 14u};
+                     chunks[k].orb_tlo, chunks[k].orb_dlo, chunks[k].chunk0, duty[k], chunks[k].size >= OWN_SLOTS ? 15u : 14u,
+                     chunk_fixed(c, (int)chunks[k].variant) ? 1u : 0u};
     };
     // 0: flat plan; 1 (default where it applies): XCD-resident scan.  (Cutting the chunks into pieces packed onto the 32
     // workgroups of an XCD, a workgroup running its pieces one after the other, was tried: 0.296 -> 0.311 ms per step.)
@@ -1797,9 +1963,13 @@ int build_slices(g2048_ctx* c) {
             for (uint32_t x = 0; x < XCDS; ++x)
                 v.push_back(slice_of(kj.first, x * parts[kj.first] + kj.second, XCDS * parts[kj.first]));
     } else {
-        const uint32_t budget = c->B < (1u << 14) ? (uint32_t)n_lds : (WG_BUDGET > n_lds ? WG_BUDGET : (uint32_t)n_lds);
-        for (size_t k = 0; k < nc; ++k) parts[k] = in_lds[k] ? 1 : 0;
-        for (size_t extra = n_lds; extra < budget; ++extra) {               // greedy: the slowest workgroup gets help
+        // one-pass mean rule: a workgroup's count field must leave the sums enough bits (k_td_update_owner), so no
+        // workgroup scans more than 2^21 / 4 records
+        const uint32_t base_parts = (c->update_rule == 1 && c->knob.mean_one_pass) ? (uint32_t)((4ull * c->B) >> 21) + 1u : 1u;
+        const uint32_t floor_wgs = (uint32_t)n_lds * base_parts;
+        const uint32_t budget = c->B < (1u << 14) ? floor_wgs : (WG_BUDGET > floor_wgs ? WG_BUDGET : floor_wgs);
+        for (size_t k = 0; k < nc; ++k) parts[k] = in_lds[k] ? base_parts : 0;
+        for (size_t extra = floor_wgs; extra < budget; ++extra) {           // greedy: the slowest workgroup gets help
             size_t worst = nc;
             for (size_t k = 0; k < nc; ++k)
                 if (in_lds[k] && (worst == nc || cost[k] / parts[k] > cost[worst] / parts[worst])) worst = k;
@@ -1907,18 +2077,21 @@ int replan(g2048_ctx* c) {
 }
 
 // workgroups of k_td_play: as many as are resident at once (occupancy x CUs), or fewer if the batch is small
-template <int N>
+template <int N, int TPB, bool HOT>
 unsigned play_grid(g2048_ctx* c) {
     if (!c->play_wgs) {
         int per_cu = 0, cus = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_td_play<N>, WG, 0) != hipSuccess || per_cu <= 0) per_cu = 2;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_td_play<N, TPB, HOT>, TPB, 0) != hipSuccess || per_cu <= 0) per_cu = HOT ? 1 : 2;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || cus <= 0) cus = 256;
         c->play_wgs = (unsigned)(per_cu * cus);
         if (c->knob.play_wgs) c->play_wgs = c->knob.play_wgs;                                 // (experiments)
     }
-    const unsigned need = grid_for(c->B);
+    const unsigned need = (unsigned)(((uint64_t)c->B + TPB - 1) / TPB);
     return need < c->play_wgs ? need : c->play_wgs;
 }
+
+// the LDS hot set pays once a workgroup has enough lanes to amortise its 88 KB copy; n >= 4 only
+bool play_hot(const g2048_ctx* c) { return c->n >= 4 && c->knob.play_hot && c->B >= c->knob.play_hot_min; }
 
 // One TD step on the context's stream: k_td_play, then the update in the selected mode.  `ev` (optional) gets an
 // event between the two parts.
@@ -1944,8 +2117,19 @@ int launch_td_step(g2048_ctx* c, float alpha, hipEvent_t ev = nullptr, hipEvent_
         if (each || c->steps_since_plan >= c->replan_interval)
             if (int rc = stats_readback(c)) return rc;
     }
-    BY_N(c, (k_td_play<N><<<play_grid<N>(c), WG, 0, c->stream>>>(c->boards, c->scores, c->rng, pn, c->label, c->flags, B, c->w, alpha, recs,
-                                                             c->auto_reset, c->stats, c->last_move, c->log)));
+#define G2048_PLAY(NN, TPB, HOT)                                                                                                      \
+    k_td_play<NN, TPB, HOT><<<play_grid<NN, TPB, HOT>(c), TPB, 0, c->stream>>>(c->boards, c->scores, c->rng, pn, c->label, c->flags, B, c->w, alpha, \
+                                                                                recs, c->auto_reset, c->stats, c->last_move, c->log)
+    if (play_hot(c)) {
+        switch (c->n) {
+            case 4: G2048_PLAY(4, PLAY_HOT_WG, true); break;
+            case 5: G2048_PLAY(5, PLAY_HOT_WG, true); break;
+            default: G2048_PLAY(6, PLAY_HOT_WG, true); break;
+        }
+    } else {
+        BY_N(c, (G2048_PLAY(N, 256, false)));
+    }
+#undef G2048_PLAY
     if (ev) (void)hipEventRecord(ev, c->stream);
     if (c->update_mode == 1) {
         if (int rc = replan(c)) return rc;
@@ -1960,16 +2144,26 @@ int launch_td_step(g2048_ctx* c, float alpha, hipEvent_t ev = nullptr, hipEvent_
         float* Ccur = alt ? c->Dcnt2 : c->Dcnt;
         float* Coth = alt ? c->Dcnt : c->Dcnt2;
         float* dacc = c->tracking ? c->delta : nullptr;
-        if (c->update_rule == 1) {      // counting pass: the same accumulation with dw = 1, into Dcnt
+        // Mean rule: counts and sums come from ONE accumulation (count bits packed under the fixed-point sums) while the
+        // count field leaves the sums 2^-18 of the largest |dw| as resolution: fewer than 2^21 adds per slot and workgroup
+        // (the planner keeps the record ranges that short).
+        // Beyond that (and for the n = 6 tail kernel) the counts take a second run of the same accumulation with dw = 1.
+        bool one_pass = false;
+        if (c->update_rule == 1) {
+            uint32_t min_parts = ~0u;
+            for (const Slice& sl : c->plan) min_parts = sl.nparts < min_parts ? sl.nparts : min_parts;
+            const uint64_t adds = (uint64_t)(c->n >= 4 ? 4 : 8) * ((B + min_parts - 1) / (min_parts ? min_parts : 1) + 4096);
+            one_pass = c->knob.mean_one_pass && !c->plan.empty() && adds < (1ull << 21);
             TdRecs ones = recs;
             ones.unit = 1;
-            BY_N(c, (k_td_update_owner<N><<<c->n_slices, OWN_WG, 0, c->stream>>>(Ccur, ones, B, c->slices, c->hits, c->wg_clock)));
+            if (!one_pass) BY_N(c, (k_td_update_owner<N><<<c->n_slices, OWN_WG, 0, c->stream>>>(Ccur, nullptr, ones, B, c->slices, c->hits, c->wg_clock)));
             if (c->n == 6) k_td_update_tail<6><<<tail_grid, OWN_WG, 0, c->stream>>>(c->Dcnt, ones, B, c->orbits.o[6].base, c->orbits.o[7].base);
         }
         // n = 2, 3: the workgroups add straight into the table, unless the sums are needed apart (mean rule, delta tracking)
         const bool flat_apart = c->n < 4 && (c->update_rule == 1 || dacc);
         float* dst = c->n >= 4 ? Dcur : (flat_apart ? c->D : c->w);
-        BY_N(c, (k_td_update_owner<N><<<c->n_slices, OWN_WG, 0, c->stream>>>(dst, recs, B, c->slices, c->hits, c->wg_clock)));
+        float* cdst = one_pass ? (c->n >= 4 ? Ccur : c->Dcnt) : nullptr;
+        BY_N(c, (k_td_update_owner<N><<<c->n_slices, OWN_WG, 0, c->stream>>>(dst, cdst, recs, B, c->slices, c->hits, c->wg_clock)));
         if (ev_owner) (void)hipEventRecord(ev_owner, c->stream);
         if (c->n == 6) k_td_update_tail<6><<<tail_grid, OWN_WG, 0, c->stream>>>(c->D, recs, B, c->orbits.o[6].base, c->orbits.o[7].base);
         if (ev_tail) (void)hipEventRecord(ev_tail, c->stream);
@@ -2500,7 +2694,18 @@ int g2048_set_update_rule(g2048_ctx* c, int rule) {
             HIP_TRY(c, hipMemsetAsync(c->Dcnt2, 0, (size_t)c->owned_total * 4, c->stream));
         }
     }
+    const bool rechunk = c->n >= 4 && c->update_rule != rule;      // the cross orbit changes its chunk size with the rule
     c->update_rule = rule;
+    if (rechunk) {
+        if (int rc = bind(c)) return rc;
+        HIP_TRY(c, hipMemsetAsync(c->statbuf, 0, STAT_BYTES, c->stream));
+        c->n_chunks = 0;
+        c->work.clear();
+        c->plan_measured = false;
+        c->replan_interval = 1;
+        c->steps_since_read = 0;
+        return build_slices(c);
+    }
     return G2048_OK;
 }
 
@@ -2509,24 +2714,30 @@ int g2048_set_update_rule(g2048_ctx* c, int rule) {
 int g2048_td_steps_kernel_ms(g2048_ctx* c, float alpha, uint32_t nsteps, float* out4) {
     if (!c || !out4) return c ? fail(c, G2048_ERR_ARG, "null buffer") : G2048_ERR_ARG;
     NEED_TABLE(c);
+    NEED(c, nsteps <= 256, "at most 256 steps per call");
     if (int rc = bind(c)) return rc;
     USE_TABLE(c);
-    hipEvent_t e[5];
-    for (auto& ev : e) HIP_TRY(c, hipEventCreate(&ev));
-    double t[4] = {0, 0, 0, 0};
+    // five events per step, all read after ONE wait at the end: the steps run back to back as in g2048_td_steps
+    std::vector<hipEvent_t> e(5 * (size_t)nsteps, nullptr);
     int rc = G2048_OK;
+    for (auto& ev : e)
+        if (rc == G2048_OK && hipEventCreate(&ev) != hipSuccess) rc = fail(c, G2048_ERR_HIP, "hipEventCreate");
     for (uint32_t s = 0; s < nsteps && rc == G2048_OK; ++s) {
-        (void)hipEventRecord(e[0], c->stream);
-        rc = launch_td_step(c, alpha, e[1], e[2], e[3]);
-        (void)hipEventRecord(e[4], c->stream);
-        if (hipEventSynchronize(e[4]) != hipSuccess) rc = fail(c, G2048_ERR_HIP, "event timing failed");
+        hipEvent_t* v = &e[5 * (size_t)s];
+        (void)hipEventRecord(v[0], c->stream);
+        rc = launch_td_step(c, alpha, v[1], v[2], v[3]);
+        (void)hipEventRecord(v[4], c->stream);
+    }
+    if (rc == G2048_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(c, G2048_ERR_HIP, "hipStreamSynchronize");
+    double t[4] = {0, 0, 0, 0};
+    for (uint32_t s = 0; s < nsteps && rc == G2048_OK; ++s)
         for (int j = 0; j < 4 && rc == G2048_OK; ++j) {
             float ms = 0;
-            if (hipEventElapsedTime(&ms, e[j], e[j + 1]) != hipSuccess) rc = fail(c, G2048_ERR_HIP, "event timing failed");
+            if (hipEventElapsedTime(&ms, e[5 * (size_t)s + j], e[5 * (size_t)s + j + 1]) != hipSuccess) rc = fail(c, G2048_ERR_HIP, "event timing failed");
             t[j] += ms;
         }
-    }
-    for (auto& ev : e) (void)hipEventDestroy(ev);
+    for (auto& ev : e)
+        if (ev) (void)hipEventDestroy(ev);
     if (rc) return rc;
     for (int j = 0; j < 4; ++j) out4[j] = nsteps ? (float)(t[j] / nsteps) : 0.0f;
     return launched(c, "k_td_play/k_td_update");

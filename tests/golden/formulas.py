@@ -90,3 +90,16 @@ def fixture_boards(played=None):
     if played is not None:
         out += [np.array(b, np.uint8) for b in played]
     return np.stack(out)
+
+
+def lookahead_draws(board, k):
+    """The sampled chance nodes of Game.look_forward (game_logic.py:221-225) for the fixtures: which k empty cells get a
+    tile and which tile (2 with probability 0.1), as a function of the BOARD only — so that the reference's depth-first
+    walk and the batched level-by-level walk draw the same tiles whatever their visiting order.
+    Returns (cells flat index [k], tiles [k])."""
+    b = np.ascontiguousarray(board, np.uint8)
+    r = np.random.RandomState(int.from_bytes(b.tobytes()[:8], 'little') % (2 ** 31))
+    empties = np.nonzero(b.reshape(16) == 0)[0]
+    cells = r.permutation(empties)[:k]
+    tiles = np.where(r.rand(k) < 0.1, 2, 1)
+    return cells, tiles

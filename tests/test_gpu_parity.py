@@ -244,7 +244,7 @@ def test_update_linearity_full_size(n):
 # ------------------------------------------------------------------ TD(0)
 
 @pytest.mark.parametrize('mode', [1, 0])
-@pytest.mark.parametrize('n', [2, 3, 4])
+@pytest.mark.parametrize('n', [2, 3, 4, 5, 6])
 def test_td_single_lane_reproduces_reference_episode(golden, n, mode):
     """Batch 1, same weights, same (r10, k) draws as the reference's QAgent.episode(): every board, action and
     score of the whole game is identical; the learned table matches within fp32 tolerance."""
@@ -328,6 +328,75 @@ def test_td_large_batch_vs_oracle_through_replans():
         helpers.check_td_step(eng, n, formulas.exact_alpha(n), formulas.weights(n, scale=2.0 ** -(4 + t % 4)))
     plan = eng.debug_owner_plan()
     assert len(plan) % 8 == 0                                                # parts come in multiples of the 8 XCDs
+    eng.close()
+
+
+@pytest.mark.parametrize('n,B', [(4, 4096), (5, 5000), (6, 1237)])
+def test_td_hot_set_path_vs_oracle(n, B, monkeypatch):
+    """k_td_play's LDS hot set (four-cell tuples with all tiles <= 32 served from an LDS copy through flat loads) forced
+    on at a small batch: mid-game boards mix hot and cold tuples, random boards of tiles 0..13 are almost all cold; every
+    step is checked against the float64 oracle as everywhere else."""
+    monkeypatch.setenv('G2048_PLAY_HOT_MIN', '1')
+    eng = Engine(B, n=n, seed=900 + n)
+    eng.set_auto_reset(False)
+    eng.step_random(30)
+    for t in range(3):
+        helpers.check_td_step(eng, n, formulas.exact_alpha(n), formulas.weights(n, scale=2.0 ** -(4 + t)))
+    r = np.random.RandomState(n)
+    boards = (r.randint(0, 14, (B, 4, 4)) * (r.rand(B, 4, 4) < 0.8)).astype(np.uint8)
+    boards[:64] = r.randint(0, 6, (64, 4, 4))                # some all-hot boards too
+    boards[:, 0, 0] = 0                                      # an empty cell and a tile: every lane has a move
+    boards[:, 1, 1] = np.maximum(boards[:, 1, 1], 1)
+    eng.set_boards(boards)
+    for t in range(2):
+        helpers.check_td_step(eng, n, formulas.exact_alpha(n), formulas.weights(n, scale=2.0 ** -(5 + t)))
+    eng.close()
+
+
+def test_td_config4_full_size_owner_path():
+    """BASELINE config 4 at its full size — 2^20 lanes, n = 5, the LDS-owner update the bench times.  Per step:
+    a slice of lanes is replayed by the float64 oracle (their choices depend only on the table before the step: boards,
+    scores, RNG, carried state and labels bit for bit), every live lane moves once, and the table's total change equals
+    8 F sum(dw) with the records' dw rebuilt from the lanes' exported state (r_learning.py:240,248)."""
+    n, B, F = 5, 1 << 20, 21
+    alpha = formulas.exact_alpha(n)
+    eng = Engine(B, n=n, seed=4)
+    eng.set_auto_reset(False)
+    eng.step_random(60)
+    lo, hi = 500000, 500000 + 8192
+    for t in range(3):
+        w = formulas.weights(n, scale=2.0 ** -(5 + t))
+        eng.set_weights(w)
+        boards0, scores0 = eng.get_boards(), eng.get_scores()
+        prev0, label0, flags0 = eng.get_carry()
+        rng0 = eng.get_rng()
+        lanes = rb.Lanes(boards0[lo:hi], scores0[lo:hi])
+        lanes.prev, lanes.label = prev0[lo:hi].copy(), label0[lo:hi].astype(np.float64)
+        lanes.has_prev, lanes.done = (flags0[lo:hi] & 1).astype(bool), (flags0[lo:hi] & 2).astype(bool)
+        draws = helpers.SpecDraws(rng0[lo:hi].copy())
+        rb.td_step(n, w.astype(np.float64).copy(), lanes, alpha, draws)
+        moves0 = eng.stats()['moves']
+        eng.td_steps(alpha, 1)
+        boards1, scores1 = eng.get_boards(), eng.get_scores()
+        prev1, label1, flags1 = eng.get_carry()
+        live = (flags0 & 2) == 0
+        assert np.array_equal(boards1[lo:hi], lanes.boards) and np.array_equal(scores1[lo:hi], lanes.scores)
+        assert np.array_equal(eng.get_rng()[lo:hi], draws.state)
+        sl_live = live[lo:hi]
+        assert np.array_equal(prev1[lo:hi][sl_live], lanes.prev[sl_live])
+        assert np.array_equal(label1[lo:hi].astype(np.float64), lanes.label)
+        assert np.array_equal((flags1[lo:hi] & 2).astype(bool), lanes.done)
+        assert eng.stats()['moves'] - moves0 == int(live.sum())              # every live lane made one move
+        # sum of the step's dw from the exported lane state (dyadic weights: labels are exact)
+        had = live & ((flags0 & 1) != 0)
+        dw1 = (scores1.astype(np.float64) - scores0 + label1.astype(np.float64) - label0.astype(np.float64)) * alpha / F
+        ended = live & ((flags1 & 2) != 0)
+        dw2 = -label1.astype(np.float64) * alpha / F
+        total = 8.0 * F * (dw1[had].sum() + dw2[ended].sum())
+        mass = 8.0 * F * (np.abs(dw1[had]).sum() + np.abs(dw2[ended]).sum())
+        got = (eng.get_weights().astype(np.float64) - w.astype(np.float64)).sum()
+        assert abs(got - total) <= 1e-6 * mass + 1e-6, (got, total)
+    assert not rb.game_over(eng.get_boards()[(eng.get_carry()[2] & 2) == 0]).any()    # no dead board stays live
     eng.close()
 
 

@@ -254,3 +254,72 @@ def golden_boards_for_lookahead():
     g = load_golden('moves.npz')
     b = g['boards'][(g['game_over'] == 0) & (g['empty_count'] > 0) & (g['boards'].reshape(len(g['boards']), 16).max(axis=1) < 12)]
     return np.ascontiguousarray(b[::97][:24])
+
+
+# ------------------------------------------------------------------ fixtures written by the reference itself (make_golden2.py)
+
+def test_look_forward_matches_reference_fixture(api, golden):
+    """Game.look_forward and _find_best_move at depth > 0 (game_logic.py:150-161,214-243) against values the reference's
+    own recursion produced, the sampled chance nodes supplied to both sides by formulas.lookahead_draws."""
+    import importlib
+    lookahead = importlib.import_module('2048_amd.lookahead')
+    g = golden('lookahead.npz')
+    n = int(g['n'])
+    agent = api.QAgent(name='t', storage='local', console='local', n=n, with_weights=False)
+    w = formulas.weights(n)
+    offs, _ = rs.feature_offsets(n)
+    agent.weights = [w[o:o + s] for o, s in zip(offs, formulas.feature_sizes(n))]
+
+    def sampler(rows, k):
+        kmax = int(k.max())
+        cells = np.full((len(rows), kmax), -1, np.int64)
+        tiles = np.ones((len(rows), kmax), np.int64)
+        for i, (row, kk) in enumerate(zip(rows, k)):
+            cells[i, :kk], tiles[i, :kk] = formulas.lookahead_draws(row, int(kk))
+        return cells, tiles
+
+    import game2048.game_logic as gl
+    saved = list(gl._SAMPLER) if hasattr(gl, '_SAMPLER') else None
+    game_mod = importlib.import_module('2048_amd.game')
+    game_mod._SAMPLER[:] = [sampler]
+    try:
+        for ci, (depth, width, since_empty) in enumerate(g['configs']):
+            got = lookahead.expectimax_values(agent.engine, g['boards'], int(depth), int(width), int(since_empty), sampler)
+            assert np.allclose(got, g['values'][ci], rtol=1e-6, atol=1e-6), (depth, width, since_empty)
+            for bi in range(0, len(g['boards']), 3):
+                game = api.Game(row=g['boards'][bi].astype(np.int32))
+                assert game._find_best_move(agent.evaluate, int(depth), int(width), int(since_empty))[0] == g['best_dir'][ci, bi]
+    finally:
+        game_mod._SAMPLER[:] = []
+    del saved
+
+
+def test_reference_written_pickles_load(api, golden, tmp_path, monkeypatch):
+    """An agent and a game pickled BY THE REFERENCE (local mode r_learning.py:176-180, s3 mode :166-175, Game.save_game
+    game_logic.py:77-80) load into this build: same parameters, same table, same values, and the game replays."""
+    import importlib
+    import shutil
+    from tests.conftest import GOLDEN
+    g = golden('ref_pickles.npz')
+
+    def check(agent):
+        assert (agent.n, agent.alpha, agent.step, agent.top_score) == (2, float(g['alpha']), int(g['step']), int(g['top_score']))
+        assert list(agent.train_history) == list(g['train_history']) and agent.weight_signature == (24,)
+        assert np.array_equal(np.concatenate([np.asarray(r, np.float32) for r in agent.weights]), g['weights'])
+        for b, v in zip(g['boards'], g['values']):
+            assert abs(agent.evaluate(b.astype(np.int32)) - v) <= 1e-5 * 24 * np.abs(g['weights']).max() + 1e-6
+        assert agent.top_game.score == int(g['game_score'])
+    check(api.QAgent.load_agent_local(os.path.join(GOLDEN, 'ref_agent_local.pkl')))
+    start = importlib.import_module('2048_amd.start')
+    monkeypatch.setattr(start, 'STORAGE', str(tmp_path))
+    os.makedirs(tmp_path / 'a')
+    os.makedirs(tmp_path / 'weights')
+    shutil.copy(os.path.join(GOLDEN, 'ref_agent_params.pkl'), tmp_path / 'a' / 'ref_agent.pkl')
+    shutil.copy(os.path.join(GOLDEN, 'ref_agent_weights.pkl'), tmp_path / 'weights' / 'ref_agent.pkl')
+    check(api.QAgent.load_agent('a/ref_agent.pkl'))
+    game = api.Game.load_game(os.path.join(GOLDEN, 'ref_game.pkl'))
+    assert game.score == int(g['game_score']) and np.array_equal(game.row, g['game_row'])
+    assert list(game.moves) == list(g['game_moves']) and len(game.tiles) == len(g['game_tiles'])
+    chain = game.replay(verbose=False)                         # show.py's replay walks exactly this record (show.py:104-128)
+    assert np.array_equal(chain[0][0], g['game_start']) and np.array_equal(chain[game.odometer][0], g['game_row'])
+    assert chain[game.odometer][1] == game.score
