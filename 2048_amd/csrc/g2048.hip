@@ -30,6 +30,10 @@
 
 using namespace g2048;
 
+// lane_sort.hip: device radix sort of (key, lane position) pairs; temp == nullptr asks for the scratch size
+extern "C" int g2048_lane_sort_pairs(void* temp, size_t* temp_bytes, const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* vals_in,
+                                     uint32_t* vals_out, uint32_t n, int begin_bit, int end_bit, hipStream_t stream);
+
 namespace {
 
 constexpr int WG = 256;
@@ -680,6 +684,18 @@ __device__ __forceinline__ void push_terminal(const TdRecs& r, const Packed& sta
     r.qdw[slot] = dw;
 }
 
+// The per-lane arrays that carry a game from one step to the next.  There are two such sets: a step that re-orders the
+// lanes (LaneSort below) reads one through the permutation and writes the other in the new order.
+struct LaneSet {
+    uint4* boards;
+    int32_t* scores;
+    ulonglong2* rng;
+    float* label;
+    uint8_t* flags;
+    uint32_t* lane_id;      // which lane of the context (0 .. B-1, the index the host sees) sits at this position
+    uint16_t* last_move;
+};
+
 // Optional per-lane game records for the first `lanes` lanes (Game.moves / Game.tiles / starting_position of
 // game_logic.py:55-66, what Game.replay and show.py's replay need).  Two slots per lane: while one game is being
 // written the previous, finished one stays readable.
@@ -731,10 +747,12 @@ __device__ __forceinline__ void log_step(const GameLog& lg, uint32_t i, uint32_t
 // Step part 1 — the body of `while not game.game_over` in QAgent.episode (r_learning.py:228-246) for every live
 // lane, all reading the same table.  `prev` is double-buffered: prev_cur holds `state`, prev_nxt receives this
 // step's afterstate, so the main record needs no copy.
+// `perm` (null on ordinary steps, when in == out): position i of the new lane order takes the lane now at position perm[i];
+// the step's records stay in the OLD order (dw1 is written at perm[i], where the update kernels find the lane's `state`).
 template <int N, int TPB, bool HOT>
-__global__ __launch_bounds__(TPB) void k_td_play(uint4* boards, int32_t* scores, ulonglong2* rng, uint4* prev_nxt, float* label, uint8_t* flags,
+__global__ __launch_bounds__(TPB) void k_td_play(LaneSet in, LaneSet out, const uint32_t* __restrict__ perm, uint4* prev_nxt,
                                                  uint32_t B, const float* __restrict__ w, float alpha, TdRecs recs, int auto_reset,
-                                                 Stats* stats, uint16_t* last_move, GameLog lg) {
+                                                 Stats* stats, GameLog lg) {
     constexpr float F = (float)Shape<N>::F;
     constexpr uint32_t WG = TPB;        // (shadows the file-wide 256: lane blocks are as wide as the workgroup)
     __shared__ WgStats ws;
@@ -763,14 +781,27 @@ __global__ __launch_bounds__(TPB) void k_td_play(uint4* boards, int32_t* scores,
     uint32_t ndirs = 0;             // directions that were open to this lane's move
     float dw_big = 0.0f;            // largest |dw| this lane emits
     if (i < B) {
-        uint8_t fl = flags[i];
+        const uint32_t src = perm ? perm[i] : i;
+        uint8_t fl = in.flags[src];
+        uint32_t lid = i;
+        if (perm || lg.lanes) lid = in.lane_id[src];
+        if (perm) out.lane_id[i] = lid;
         float dw1 = 0.0f;
         uint32_t lm = 0;        // what this lane did: bits 0-1 direction, 2 moved, 4-7 new tile's cell, 8-9 new tile, 10 spawned, 11 game ended
-        if (!(fl & DONE)) {
-            Board b = ld_board(boards, i);
-            Rng g = ld_rng(rng, i);
-            int32_t score = scores[i];
-            float old_label = label[i];
+        if (fl & DONE) {
+            if (perm) {         // a finished lane moves with the others
+                out.boards[i] = in.boards[src];
+                out.rng[i] = in.rng[src];
+                out.scores[i] = in.scores[src];
+                out.label[i] = in.label[src];
+                out.flags[i] = fl;
+                prev_nxt[i] = recs.state1[src];
+            }
+        } else {
+            Board b = ld_board(in.boards, src);
+            Rng g = ld_rng(in.rng, src);
+            int32_t score = in.scores[src];
+            float old_label = in.label[src];
             Moves4 mv = all_moves(b);
             Choice c;
             if constexpr (HOT)
@@ -816,11 +847,11 @@ __global__ __launch_bounds__(TPB) void k_td_play(uint4* boards, int32_t* scores,
             } else {
                 // a dead board was loaded: the reference's loop would not run; only the terminal update remains
                 over = true;
-                prev_nxt[i] = recs.state1[i];
+                prev_nxt[i] = recs.state1[src];
                 if (fl & HAS_PREV) {
                     const float dw2 = -old_label * alpha / F;
                     if (isfinite(dw2)) {
-                        push_terminal(recs, ld_packed(recs.state1, i), dw2);
+                        push_terminal(recs, ld_packed(recs.state1, src), dw2);
                         dw_big = fabsf(dw2);
                     } else {
                         atomicAdd(&ws.nonfinite, 1u);
@@ -840,12 +871,12 @@ __global__ __launch_bounds__(TPB) void k_td_play(uint4* boards, int32_t* scores,
                     fl |= DONE;
                 }
             }
-            if (i < lg.lanes) log_step(lg, i, lm, moved, over, final_score, over && auto_reset, b);
-            st_board(boards, i, b);
-            st_rng(rng, i, g);
-            scores[i] = score;
-            label[i] = old_label;
-            flags[i] = fl;
+            if (lid < lg.lanes) log_step(lg, lid, lm, moved, over, final_score, over && auto_reset, b);
+            st_board(out.boards, i, b);
+            st_rng(out.rng, i, g);
+            out.scores[i] = score;
+            out.label[i] = old_label;
+            out.flags[i] = fl;
         }
         // a record whose dw is not finite (a table poisoned with inf / NaN) is dropped and counted: the fixed-point sums
         // of the LDS-owner update have no encoding for it
@@ -853,8 +884,8 @@ __global__ __launch_bounds__(TPB) void k_td_play(uint4* boards, int32_t* scores,
             atomicAdd(&ws.nonfinite, 1u);
             dw1 = 0.0f;
         }
-        recs.dw1[i] = dw1;
-        last_move[i] = (uint16_t)lm;
+        recs.dw1[src] = dw1;
+        out.last_move[i] = (uint16_t)lm;
         dw_big = fmaxf(dw_big, fabsf(dw1));
     }
     if (dw_big > 0.0f) atomicMax(&ws.dw_max_bits, __float_as_uint(dw_big));
@@ -1064,8 +1095,12 @@ __device__ __forceinline__ void own_run(float* acc, const Slice& s, const TdRecs
         constexpr int NI = V == 4 ? 1 : 4, U = 4;
         const OrbitIdx oi = orbit_idx(recs.oidx, B);
         const uint32_t lo_rel = s.tlo - s.orb_tlo;
-        const uint32_t begin = (uint32_t)((uint64_t)B * s.part / s.nparts), end = (uint32_t)((uint64_t)B * (s.part + 1) / s.nparts);
-        for (uint32_t base0 = begin; base0 < end; base0 += OWN_WG * U) {
+        // a part takes every nparts-th block of records, not one contiguous range: the lanes may be ordered by board
+        // pattern (LaneSort), and neighbouring records then hit the same few slots
+        constexpr uint32_t BLK = OWN_WG * U;
+        const uint32_t nblk = (B + BLK - 1) / BLK, end = B;
+        for (uint32_t blk = s.part; blk < nblk; blk += s.nparts) {
+            const uint32_t base0 = blk * BLK;
             uint32_t idx[U][NI];
             float dw[U];
 #pragma unroll
@@ -1092,8 +1127,10 @@ __device__ __forceinline__ void own_run(float* acc, const Slice& s, const TdRecs
         }
     } else {   // main records: this part's share of the lanes, OWN_UNROLL records per thread in flight; the loop bounds are
         // wave-uniform
-        const uint32_t begin = (uint32_t)((uint64_t)B * s.part / s.nparts), end = (uint32_t)((uint64_t)B * (s.part + 1) / s.nparts);
-        for (uint32_t base0 = begin; base0 < end; base0 += OWN_WG * OWN_UNROLL) {
+        constexpr uint32_t BLK = OWN_WG * OWN_UNROLL;
+        const uint32_t nblk = (B + BLK - 1) / BLK, end = B;
+        for (uint32_t blk = s.part; blk < nblk; blk += s.nparts) {
+            const uint32_t base0 = blk * BLK;
             uint4 st[OWN_UNROLL];
             float dw[OWN_UNROLL];
 #pragma unroll
@@ -1171,7 +1208,7 @@ __global__ __launch_bounds__(OWN_WG) void k_td_update_owner(float* dst, float* c
     if (fixed) {
         const float big = recs.unit ? 1.0f : __uint_as_float(*recs.dwmax);
         int e = big > 0.0f ? ilogbf(big) + 1 : 0;
-        const uint32_t part_recs = (B + s.nparts - 1) / s.nparts + *recs.qcount;
+        const uint32_t part_recs = (B + s.nparts - 1) / s.nparts + 4096u + *recs.qcount;      // (blocks of <= 4096 records, dealt round-robin)
         const uint32_t per_rec = N >= 4 ? 4u : 8u;          // adds one record can make to one slot
         const int add_bits = 32 - __clz((int)(part_recs < (1u << 28) ? per_rec * part_recs : 0x7FFFFFFFu));
         if (cdst) cbits = (uint32_t)add_bits + 1u;
@@ -1380,6 +1417,66 @@ __global__ __launch_bounds__(OWN_WG) void k_td_update_tail(float* D, TdRecs recs
         if (keys[j] != TAIL_EMPTY && vals[j] != 0.0f) __hip_atomic_fetch_add(&D[keys[j]], vals[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// ------------------------------------------------------------------------------------------------ lane order (LaneSort)
+// k_td_play is bound by L1 misses of its table gathers: a CU's 32 KB L1 sees ~4 000 unrelated boards per launch.  Which
+// cache lines a board's COLD tuples touch is decided by where its big tiles sit (the small ones come and go every move),
+// so lanes with the same big-tile pattern use the same lines.  Every few steps the lanes are therefore re-ordered by
+// that pattern: a 48-bit key per lane (3 bits per cell: how far the tile is above SORT_TILE, else 0), one radix sort,
+// and the next k_td_play reads its lanes through the permutation and writes them back in the new order (no separate
+// copy pass).  The host never sees the order: lane_id travels with the lane and every lane-addressed entry point of the
+// ABI first restores the identity order (k_restore_order).
+constexpr uint32_t SORT_TILE = 5;
+
+__global__ __launch_bounds__(WG) void k_iota(uint32_t* v, uint32_t n) {
+    uint32_t i = blockIdx.x * WG + threadIdx.x;
+    if (i < n) v[i] = i;
+}
+
+__global__ __launch_bounds__(WG) void k_sort_keys(const uint4* boards, uint32_t B, uint64_t* keys) {
+    uint32_t i = blockIdx.x * WG + threadIdx.x;
+    if (i >= B) return;
+    const Board b = ld_board(boards, i);
+    uint64_t key = 0;           // 3 bits per cell, row-major: 0 for a tile <= SORT_TILE, else tile - SORT_TILE (7 = that and above)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int col = 0; col < 4; ++col) {
+            const uint32_t v = (b.r[r] >> (8 * col)) & 0xFFu;
+            const uint32_t code = v > SORT_TILE ? (v - SORT_TILE > 7u ? 7u : v - SORT_TILE) : 0u;
+            key = (key << 3) | code;
+        }
+    keys[i] = key;
+}
+constexpr int SORT_KEY_BITS = 48;
+
+struct CarrySet {       // the `state` of QAgent.episode and its orbit indices (prev[cur], oidx[cur])
+    uint4* prev;
+    uint8_t* oidx;
+};
+
+// position j holds lane lane_id[j]: put everything back where the host expects it
+template <bool ORBITS>
+__global__ __launch_bounds__(WG) void k_restore_order(LaneSet in, LaneSet out, CarrySet cin, CarrySet cout, uint32_t B) {
+    uint32_t j = blockIdx.x * WG + threadIdx.x;
+    if (j >= B) return;
+    const uint32_t id = in.lane_id[j];
+    out.boards[id] = in.boards[j];
+    out.scores[id] = in.scores[j];
+    out.rng[id] = in.rng[j];
+    out.label[id] = in.label[j];
+    out.flags[id] = in.flags[j];
+    out.last_move[id] = in.last_move[j];
+    out.lane_id[id] = id;
+    cout.prev[id] = cin.prev[j];
+    if (ORBITS) {
+        const OrbitIdx a = orbit_idx(cin.oidx, B), b = orbit_idx(cout.oidx, B);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) b.q[(size_t)v * B + id] = a.q[(size_t)v * B + j];
+        b.x[id] = a.x[j];
+        b.c[id] = a.c[j];
+    }
+}
+
 // init_weights (r_learning.py:139-149): U[0, scale) per slot, counter-based so any rank can build the same table
 __global__ __launch_bounds__(WG) void k_weights_init(float* w, uint64_t count, uint64_t seed, float scale) {
     uint64_t i = (uint64_t)blockIdx.x * WG + threadIdx.x;
@@ -1465,6 +1562,17 @@ struct g2048_ctx {
     float* qdw = nullptr;
     uint32_t* qcount = nullptr;         // [6]: this / next step's queue length, largest |dw| bits, k_td_play block counter
     uint16_t* last_move = nullptr;      // what every lane did in the latest TD step (g2048_get_last_move)
+    // lane order (LaneSort): boards / scores / rng / label / flags / last_move / lane_id above are the CURRENT set; `alt` is
+    // the other one (allocated with the first re-ordering)
+    uint32_t* lane_id = nullptr;
+    LaneSet alt = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool permuted = false;              // the lanes are not in identity order
+    uint32_t sort_every = 0;            // re-order the lanes every this many TD steps (0 = never)
+    uint32_t steps_since_sort = 0;
+    uint64_t *sort_keys = nullptr, *sort_keys_out = nullptr;
+    uint32_t *sort_iota = nullptr, *sort_perm = nullptr;
+    void* sort_temp = nullptr;
+    size_t sort_temp_bytes = 0;
     GameLog log = {0, 0, nullptr, nullptr, nullptr};
     uint32_t step_parity = 0;
     float *w = nullptr, *w0 = nullptr, *delta = nullptr;
@@ -1501,6 +1609,8 @@ struct g2048_ctx {
         double add_cost = 3.0, thr = 0.01, fixed_ratio = 0.25;
         int plan_feedback = 1, plan_xcd = 1, debug_plan = 0;
         unsigned play_wgs = 0;
+        uint32_t sort_every = 16;       // default of g2048_set_lane_sort for new contexts (G2048_SORT_EVERY); 0 = never
+        uint32_t sort_min_batch = 1u << 17;     // smaller batches keep their lane order
         int mean_one_pass = 1;          // per-slot mean rule: counts packed beside the sums (0: always two accumulation passes)
         int play_hot = 0;               // 1: k_td_play reads the hot four-cell tuples from an LDS copy (n >= 4, big batches); measured, not faster
         uint32_t play_hot_min = 1u << 16;   // smallest batch that takes that path (a workgroup copies 88 KB per launch)
@@ -1592,6 +1702,8 @@ void read_knobs(g2048_ctx* c) {
     if (const char* e = getenv("G2048_PLAY_WGS")) k.play_wgs = (unsigned)atoi(e);
     if (const char* e = getenv("G2048_PLAY_HOT")) k.play_hot = atoi(e);
     if (const char* e = getenv("G2048_MEAN_ONE_PASS")) k.mean_one_pass = atoi(e);
+    if (const char* e = getenv("G2048_SORT_EVERY")) k.sort_every = (uint32_t)atoi(e);
+    if (const char* e = getenv("G2048_SORT_MIN")) k.sort_min_batch = (uint32_t)atoi(e);
     if (const char* e = getenv("G2048_PLAY_HOT_MIN")) k.play_hot_min = (uint32_t)atoi(e);
 }
 
@@ -1635,6 +1747,66 @@ int dalloc(g2048_ctx* c, T** p, size_t count) {
     if (e != hipSuccess) return fail(c, G2048_ERR_NOMEM, "hipMalloc", e);
     return G2048_OK;
 }
+
+// ---- lane order (LaneSort): see k_sort_keys
+LaneSet current_set(g2048_ctx* c) { return LaneSet{c->boards, c->scores, c->rng, c->label, c->flags, c->lane_id, c->last_move}; }
+
+void adopt_set(g2048_ctx* c, const LaneSet& s) {
+    c->boards = s.boards; c->scores = s.scores; c->rng = s.rng; c->label = s.label; c->flags = s.flags; c->lane_id = s.lane_id; c->last_move = s.last_move;
+}
+
+int lane_sort_prepare(g2048_ctx* c) {
+    if (c->alt.boards) return G2048_OK;
+    const size_t B = c->B;
+    int rc;
+    if ((rc = dalloc(c, &c->alt.boards, B)) || (rc = dalloc(c, &c->alt.scores, B)) || (rc = dalloc(c, &c->alt.rng, B)) ||
+        (rc = dalloc(c, &c->alt.label, B)) || (rc = dalloc(c, &c->alt.flags, B)) || (rc = dalloc(c, &c->alt.lane_id, B)) ||
+        (rc = dalloc(c, &c->alt.last_move, B)) || (rc = dalloc(c, &c->sort_keys, B)) || (rc = dalloc(c, &c->sort_keys_out, B)) ||
+        (rc = dalloc(c, &c->sort_iota, B)) || (rc = dalloc(c, &c->sort_perm, B)))
+        return rc;
+    HIP_TRY(c, hipMemsetAsync(c->alt.last_move, 0, B * 2, c->stream));
+    k_iota<<<grid_for(B), WG, 0, c->stream>>>(c->sort_iota, c->B);
+    size_t bytes = 0;
+    if (g2048_lane_sort_pairs(nullptr, &bytes, c->sort_keys, c->sort_keys_out, c->sort_iota, c->sort_perm, c->B, 0, SORT_KEY_BITS, c->stream) != 0)
+        return fail(c, G2048_ERR_HIP, "radix sort: scratch size query failed");
+    hipError_t e = hipMalloc(&c->sort_temp, bytes ? bytes : 16);
+    if (e != hipSuccess) return fail(c, G2048_ERR_NOMEM, "hipMalloc(sort scratch)", e);
+    c->sort_temp_bytes = bytes;
+    return G2048_OK;
+}
+
+// keys of the current boards -> sort_perm: position i of the new order takes the lane now at position sort_perm[i]
+int lane_sort_permutation(g2048_ctx* c) {
+    if (int rc = lane_sort_prepare(c)) return rc;
+    k_sort_keys<<<grid_for(c->B), WG, 0, c->stream>>>(c->boards, c->B, c->sort_keys);
+    size_t bytes = c->sort_temp_bytes;
+    if (g2048_lane_sort_pairs(c->sort_temp, &bytes, c->sort_keys, c->sort_keys_out, c->sort_iota, c->sort_perm, c->B, 0, SORT_KEY_BITS, c->stream) != 0)
+        return fail(c, G2048_ERR_HIP, "radix sort failed");
+    return G2048_OK;
+}
+
+// every entry point that addresses lanes by index calls this first: back to identity order (a no-op unless a TD step
+// re-ordered the lanes since)
+int ensure_identity(g2048_ctx* c) {
+    if (!c->permuted) return G2048_OK;
+    if (int rc = lane_sort_prepare(c)) return rc;
+    const CarrySet cin{c->prev[c->cur], c->oidx[c->cur]}, cout{c->prev[c->cur ^ 1], c->oidx[c->cur ^ 1]};
+    if (c->n >= 4)
+        k_restore_order<true><<<grid_for(c->B), WG, 0, c->stream>>>(current_set(c), c->alt, cin, cout, c->B);
+    else
+        k_restore_order<false><<<grid_for(c->B), WG, 0, c->stream>>>(current_set(c), c->alt, cin, cout, c->B);
+    const LaneSet was = current_set(c);
+    adopt_set(c, c->alt);
+    c->alt = was;
+    c->cur ^= 1;                    // the carried state now lives in the other half of prev / oidx
+    c->permuted = false;
+    c->steps_since_sort = 0;
+    return launched(c, "k_restore_order");
+}
+#define NEED_IDENTITY(c)                     \
+    do {                                     \
+        if (int rc_ = ensure_identity(c)) return rc_; \
+    } while (0)
 
 // dispatch on the n-tuple size
 #define BY_N(c, EXPR)                                                      \
@@ -2117,9 +2289,16 @@ int launch_td_step(g2048_ctx* c, float alpha, hipEvent_t ev = nullptr, hipEvent_
         if (each || c->steps_since_plan >= c->replan_interval)
             if (int rc = stats_readback(c)) return rc;
     }
+    // lane re-ordering (LaneSort): when due, this step's k_td_play reads the lanes through the sorted permutation
+    const uint32_t* perm = nullptr;
+    LaneSet lin = current_set(c), lout = lin;
+    if (c->sort_every && c->n >= 4 && B >= c->knob.sort_min_batch && ++c->steps_since_sort >= c->sort_every) {
+        if (int rc = lane_sort_permutation(c)) return rc;
+        perm = c->sort_perm;
+        lout = c->alt;
+    }
 #define G2048_PLAY(NN, TPB, HOT)                                                                                                      \
-    k_td_play<NN, TPB, HOT><<<play_grid<NN, TPB, HOT>(c), TPB, 0, c->stream>>>(c->boards, c->scores, c->rng, pn, c->label, c->flags, B, c->w, alpha, \
-                                                                                recs, c->auto_reset, c->stats, c->last_move, c->log)
+    k_td_play<NN, TPB, HOT><<<play_grid<NN, TPB, HOT>(c), TPB, 0, c->stream>>>(lin, lout, perm, pn, B, c->w, alpha, recs, c->auto_reset, c->stats, c->log)
     if (play_hot(c)) {
         switch (c->n) {
             case 4: G2048_PLAY(4, PLAY_HOT_WG, true); break;
@@ -2130,6 +2309,12 @@ int launch_td_step(g2048_ctx* c, float alpha, hipEvent_t ev = nullptr, hipEvent_
         BY_N(c, (G2048_PLAY(N, 256, false)));
     }
 #undef G2048_PLAY
+    if (perm) {
+        adopt_set(c, lout);
+        c->alt = lin;
+        c->permuted = true;
+        c->steps_since_sort = 0;
+    }
     if (ev) (void)hipEventRecord(ev, c->stream);
     if (c->update_mode == 1) {
         if (int rc = replan(c)) return rc;
@@ -2152,7 +2337,7 @@ int launch_td_step(g2048_ctx* c, float alpha, hipEvent_t ev = nullptr, hipEvent_
         if (c->update_rule == 1) {
             uint32_t min_parts = ~0u;
             for (const Slice& sl : c->plan) min_parts = sl.nparts < min_parts ? sl.nparts : min_parts;
-            const uint64_t adds = (uint64_t)(c->n >= 4 ? 4 : 8) * ((B + min_parts - 1) / (min_parts ? min_parts : 1) + 4096);
+            const uint64_t adds = (uint64_t)(c->n >= 4 ? 4 : 8) * ((B + min_parts - 1) / (min_parts ? min_parts : 1) + 8192);
             one_pass = c->knob.mean_one_pass && !c->plan.empty() && adds < (1ull << 21);
             TdRecs ones = recs;
             ones.unit = 1;
@@ -2263,7 +2448,9 @@ int g2048_destroy(g2048_ctx* c) {
         if (c->parent->last_user == c) c->parent->last_user = nullptr;
     }
     void* bufs[] = {c->log.moves, c->log.start, c->log.meta, c->boards, c->scores, c->rng, c->prev[0], c->prev[1], c->oidx[0], c->oidx[1], c->label, c->flags, c->dw1, c->qstate,
-                    c->qdw,    c->qcount, c->last_move, c->w,      c->w0,  c->delta,   c->stats,   c->scratch, c->slices, c->statbuf, c->D, c->Dcnt, c->D2, c->Dcnt2, c->pack};
+                    c->qdw,    c->qcount, c->last_move, c->w,      c->w0,  c->delta,   c->stats,   c->scratch, c->slices, c->statbuf, c->D, c->Dcnt, c->D2, c->Dcnt2, c->pack, c->lane_id,
+                    c->alt.boards, c->alt.scores, c->alt.rng, c->alt.label, c->alt.flags, c->alt.lane_id, c->alt.last_move,
+                    c->sort_keys, c->sort_keys_out, c->sort_iota, c->sort_perm, c->sort_temp};
     for (void* p : bufs)
         if (p && (p != (void*)c->w || c->owns_table)) (void)hipFree(p);
     if (c->h_stat) (void)hipHostFree(c->h_stat);
@@ -2323,7 +2510,7 @@ static int create_impl(int device, uint32_t batch, int n_tuple, uint64_t seed, u
     if ((rc = dalloc(c, &c->boards, B)) || (rc = dalloc(c, &c->scores, B)) || (rc = dalloc(c, &c->rng, B)) ||
         (rc = dalloc(c, &c->prev[0], B)) || (rc = dalloc(c, &c->prev[1], B)) || (rc = dalloc(c, &c->label, B)) ||
         (rc = dalloc(c, &c->flags, B)) || (rc = dalloc(c, &c->dw1, B)) || (rc = dalloc(c, &c->qstate, B)) || (rc = dalloc(c, &c->qdw, B)) ||
-        (rc = dalloc(c, &c->qcount, 8)) || (rc = dalloc(c, &c->last_move, B)) ||
+        (rc = dalloc(c, &c->qcount, 8)) || (rc = dalloc(c, &c->last_move, B)) || (rc = dalloc(c, &c->lane_id, B)) ||
         (rc = dalloc(c, &c->stats, 1)))
         return bail(rc);
     if (n_tuple >= 4 && ((rc = dalloc(c, &c->oidx[0], OIDX_BYTES_PER_LANE * B)) || (rc = dalloc(c, &c->oidx[1], OIDX_BYTES_PER_LANE * B)))) return bail(rc);
@@ -2346,6 +2533,8 @@ static int create_impl(int device, uint32_t batch, int n_tuple, uint64_t seed, u
         hipMemsetAsync(c->qcount, 0, 32, c->stream) != hipSuccess || hipMemsetAsync(c->last_move, 0, B * 2, c->stream) != hipSuccess || hipMemsetAsync(c->dw1, 0, B * 4, c->stream) != hipSuccess ||
         (slots && !parent && hipMemsetAsync(c->w, 0, slots * sizeof(float), c->stream) != hipSuccess))
         return bail(G2048_ERR_HIP);
+    k_iota<<<grid_for(B), WG, 0, c->stream>>>(c->lane_id, batch);
+    c->sort_every = c->knob.sort_every;
     k_seed<<<grid_for(B), WG, 0, c->stream>>>(c->rng, batch, seed, lane0);
     k_new_games<<<grid_for(B), WG, 0, c->stream>>>(c->boards, c->scores, c->rng, c->label, c->flags, batch);
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) {
@@ -2392,11 +2581,13 @@ int g2048_timer_stop(g2048_ctx* c, float* ms) {
     int g2048_set_##name(g2048_ctx* c, const type* src) {                                          \
         if (!c || !src) return c ? fail(c, G2048_ERR_ARG, "null buffer") : G2048_ERR_ARG;          \
         if (int rc = bind(c)) return rc;                                                           \
+        NEED_IDENTITY(c);                                                                          \
         return h2d(c, c->field, src, (size_t)c->B * (per) * sizeof(type));                         \
     }                                                                                              \
     int g2048_get_##name(g2048_ctx* c, type* dst) {                                                \
         if (!c || !dst) return c ? fail(c, G2048_ERR_ARG, "null buffer") : G2048_ERR_ARG;          \
         if (int rc = bind(c)) return rc;                                                           \
+        NEED_IDENTITY(c);                                                                          \
         return d2h(c, dst, c->field, (size_t)c->B * (per) * sizeof(type));                         \
     }
 
@@ -2407,6 +2598,7 @@ IO_PAIR(rng, rng, uint64_t, 2)
 int g2048_get_carry(g2048_ctx* c, uint8_t* prev, float* label, uint8_t* flags) {
     if (!c) return G2048_ERR_ARG;
     if (int rc = bind(c)) return rc;
+    NEED_IDENTITY(c);
     int rc = G2048_OK;
     if (prev) {
         if ((rc = d2h(c, prev, c->prev[c->cur], (size_t)c->B * 16))) return rc;
@@ -2435,6 +2627,7 @@ int g2048_clear_carry(g2048_ctx* c) {
 int g2048_reset(g2048_ctx* c) {
     if (!c) return G2048_ERR_ARG;
     if (int rc = bind(c)) return rc;
+    NEED_IDENTITY(c);
     c->replan_interval = 1;         // the tile distribution restarts: follow it closely again
     k_new_games<<<grid_for(c->B), WG, 0, c->stream>>>(c->boards, c->scores, c->rng, c->label, c->flags, c->B);
     if (c->log.lanes) k_log_init<<<grid_for(c->log.lanes), WG, 0, c->stream>>>(c->log, c->boards, c->flags);
@@ -2450,6 +2643,7 @@ int g2048_set_auto_reset(g2048_ctx* c, int on) {
 int g2048_move_all(g2048_ctx* c, uint8_t* after, int32_t* reward, uint8_t* changed) {
     if (!c || !after || !reward || !changed) return c ? fail(c, G2048_ERR_ARG, "null buffer") : G2048_ERR_ARG;
     if (int rc = bind(c)) return rc;
+    NEED_IDENTITY(c);
     const size_t B = c->B;
     if (int rc = ensure_scratch(c, B * (64 + 16 + 1))) return rc;
     uint4* d_after = (uint4*)c->scratch;
@@ -2465,6 +2659,7 @@ int g2048_move_all(g2048_ctx* c, uint8_t* after, int32_t* reward, uint8_t* chang
 int g2048_apply_moves(g2048_ctx* c, const uint8_t* dirs, uint8_t* moved) {
     if (!c || !dirs) return c ? fail(c, G2048_ERR_ARG, "null buffer") : G2048_ERR_ARG;
     if (int rc = bind(c)) return rc;
+    NEED_IDENTITY(c);
     const size_t B = c->B;
     if (int rc = ensure_scratch(c, 2 * B)) return rc;
     uint8_t* d_dirs = (uint8_t*)c->scratch;
@@ -2479,6 +2674,7 @@ int g2048_apply_moves(g2048_ctx* c, const uint8_t* dirs, uint8_t* moved) {
 int g2048_terminal(g2048_ctx* c, uint8_t* over, uint8_t* n_empty, uint8_t* n_pairs) {
     if (!c) return G2048_ERR_ARG;
     if (int rc = bind(c)) return rc;
+    NEED_IDENTITY(c);
     const size_t B = c->B;
     if (int rc = ensure_scratch(c, 3 * B)) return rc;
     uint8_t* d = (uint8_t*)c->scratch;
@@ -2493,6 +2689,7 @@ int g2048_terminal(g2048_ctx* c, uint8_t* over, uint8_t* n_empty, uint8_t* n_pai
 
 static int spawn_impl(g2048_ctx* c, const uint8_t* in_r10, const uint8_t* in_k, uint8_t* out_r10, uint8_t* out_k) {
     if (int rc = bind(c)) return rc;
+    NEED_IDENTITY(c);
     const size_t B = c->B;
     if (int rc = ensure_scratch(c, 4 * B)) return rc;
     uint8_t* d = (uint8_t*)c->scratch;
@@ -2568,6 +2765,7 @@ int g2048_features(g2048_ctx* c, int32_t* out) {
     if (!c || !out) return c ? fail(c, G2048_ERR_ARG, "null buffer") : G2048_ERR_ARG;
     NEED_TABLE(c);
     if (int rc = bind(c)) return rc;
+    NEED_IDENTITY(c);
     const size_t bytes = (size_t)c->B * c->F * 4;
     if (int rc = ensure_scratch(c, bytes)) return rc;
     BY_N(c, (k_features<N><<<grid_for(c->B), WG, 0, c->stream>>>(c->boards, c->B, (int32_t*)c->scratch)));
@@ -2606,6 +2804,7 @@ int g2048_evaluate(g2048_ctx* c, float* value) {
     if (!c || !value) return c ? fail(c, G2048_ERR_ARG, "null buffer") : G2048_ERR_ARG;
     NEED_TABLE(c);
     if (int rc = bind(c)) return rc;
+    NEED_IDENTITY(c);
     USE_TABLE(c);
     if (int rc = ensure_scratch(c, (size_t)c->B * 4)) return rc;
     BY_N(c, (k_evaluate<N><<<grid_for(c->B), WG, 0, c->stream>>>(c->boards, c->B, c->w, (float*)c->scratch)));
@@ -2617,6 +2816,7 @@ int g2048_eval_select(g2048_ctx* c, float* value, uint8_t* action, float* values
     if (!c || ((value == nullptr) != (action == nullptr))) return c ? fail(c, G2048_ERR_ARG, "null buffer") : G2048_ERR_ARG;
     NEED_TABLE(c);
     if (int rc = bind(c)) return rc;
+    NEED_IDENTITY(c);
     USE_TABLE(c);
     const size_t B = c->B;
     if (int rc = ensure_scratch(c, B * (16 + 4 + 1))) return rc;
@@ -2658,6 +2858,13 @@ int g2048_td_steps(g2048_ctx* c, float alpha, uint32_t nsteps) {
     for (uint32_t s = 0; s < nsteps; ++s)
         if (int rc = launch_td_step(c, alpha)) return rc;
     return launched(c, "k_td_play/k_td_update");
+}
+
+int g2048_set_lane_sort(g2048_ctx* c, uint32_t every) {
+    if (!c) return G2048_ERR_ARG;
+    c->sort_every = every;
+    c->steps_since_sort = 0;
+    return G2048_OK;
 }
 
 int g2048_set_update_mode(g2048_ctx* c, int mode) {
@@ -2776,6 +2983,7 @@ int g2048_debug_owner_plan(g2048_ctx* c, uint64_t* out, uint32_t capacity, uint3
 int g2048_get_last_move(g2048_ctx* c, uint16_t* out) {
     if (!c || !out) return c ? fail(c, G2048_ERR_ARG, "null buffer") : G2048_ERR_ARG;
     if (int rc = bind(c)) return rc;
+    NEED_IDENTITY(c);
     return d2h(c, out, c->last_move, (size_t)c->B * 2);
 }
 
@@ -2783,6 +2991,7 @@ int g2048_log_enable(g2048_ctx* c, uint32_t lanes, uint32_t capacity) {
     if (!c) return G2048_ERR_ARG;
     NEED(c, lanes <= c->B && capacity <= (1u << 20) && (lanes == 0) == (capacity == 0), "bad log geometry");
     if (int rc = bind(c)) return rc;
+    NEED_IDENTITY(c);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (c->log.moves) (void)hipFree(c->log.moves);
     if (c->log.start) (void)hipFree(c->log.start);

@@ -224,6 +224,10 @@ class Engine:
         self._c(self.lib.g2048_log_game(self.ctx, int(lane), int(slot), _buf(moves), _buf(start)))
         return moves, start
 
+    def set_lane_sort(self, every):
+        """Re-order the lanes by their big-tile pattern every `every` TD steps (0 = never); invisible to the host."""
+        self._c(self.lib.g2048_set_lane_sort(self.ctx, int(every)))
+
     def set_update_mode(self, mode):
         """1 = LDS-owner update kernel (default), 0 = global fp32 atomics."""
         self._c(self.lib.g2048_set_update_mode(self.ctx, int(mode)))
