@@ -10,7 +10,7 @@ import os
 from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_uint8, c_uint32, c_uint64, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'lib2048_hip.so')
+LIB_PATH = os.environ.get('G2048_LIB') or os.path.join(HERE, 'lib2048_hip.so')        # (G2048_LIB: experiment builds)
 
 OK, ERR_ARG, ERR_HIP, ERR_NOMEM, ERR_STATE, ERR_NODEV, ERR_COMM = 0, -1, -2, -3, -4, -5, -6
 COMM_ID_BYTES = 128

@@ -320,7 +320,11 @@ __global__ __launch_bounds__(WG) void k_features(const uint4* boards, uint32_t B
 // One table entry.  (Forcing the scalar-base + 32-bit-vector-offset form of global_load — an opaque 32-bit byte offset,
 // so that a pending gather holds one address register instead of a 64-bit pair — was measured: same register count after
 // allocation, k_td_play 0.200 -> 0.210 ms.  Plain indexing it is.)
+#ifdef G2048_EXP_NOGATHER        // (experiment: what k_td_play costs without its table reads)
+__device__ __forceinline__ float ld_w(const float* __restrict__ w, uint32_t slot) { return __uint_as_float(0x30000000u | (slot & 0xFFFFu)); }
+#else
 __device__ __forceinline__ float ld_w(const float* __restrict__ w, uint32_t slot) { return w[slot]; }
+#endif
 
 template <int N>
 __device__ __forceinline__ float value_of(const float* __restrict__ w, const Board& b) {
@@ -752,7 +756,7 @@ __device__ __forceinline__ void log_step(const GameLog& lg, uint32_t i, uint32_t
 template <int N, int TPB, bool HOT>
 __global__ __launch_bounds__(TPB) void k_td_play(LaneSet in, LaneSet out, const uint32_t* __restrict__ perm, uint4* prev_nxt,
                                                  uint32_t B, const float* __restrict__ w, float alpha, TdRecs recs, int auto_reset,
-                                                 Stats* stats, GameLog lg) {
+                                                 Stats* stats, GameLog lg, uint32_t static_rounds) {
     constexpr float F = (float)Shape<N>::F;
     constexpr uint32_t WG = TPB;        // (shadows the file-wide 256: lane blocks are as wide as the workgroup)
     __shared__ WgStats ws;
@@ -764,16 +768,28 @@ __global__ __launch_bounds__(TPB) void k_td_play(LaneSet in, LaneSet out, const 
         *recs.dwmax_next = 0;
         *recs.blocks_next = 0;
     }
-    // Persistent workgroups: the grid is what the chip holds at once (play_grid) and a workgroup takes lane blocks of 256
-    // from a counter until none is left — no workgroup launches and one statistics flush per workgroup instead of one
-    // per block, and the hardware's balance (a free slot takes the next block) is kept.  One atomic per block (4 096 per
-    // launch at 2^20 lanes; per-wave hand-out would be 16 384 on one address, which serialises at ~10 ns each).
+    // Persistent workgroups: the grid is what the chip holds at once (play_grid) and a workgroup takes lane blocks from a
+    // counter until none is left — the hardware's balance (a free slot takes the next block) is kept, no workgroup
+    // launches, one statistics flush per workgroup.  The first `static_rounds` blocks of a workgroup are g, g + G, ... (no
+    // counter, no barrier: its waves run on independently).  The counter is read ONE BLOCK AHEAD: the returning atomic is
+    // issued before the block's loads and stores, so that waiting for it at the next hand-out does not wait for those
+    // stores (vmcnt retires in order).  Measured at 2^20 lanes, n = 5: all rounds from the counter 0.213-0.230 ms, all but
+    // one static 0.194-0.218 ms, all static 0.230-0.242 ms (gpurun_out r02p).
     __shared__ uint32_t next_block[2];
     const uint32_t nblocks = (B + WG - 1) / WG;
+    uint32_t ahead = 0;
+    if (threadIdx.x == 0 && static_rounds == 0) ahead = atomicAdd(recs.blocks, 1u);
     for (uint32_t it = 0;; ++it) {
-    if (threadIdx.x == 0) next_block[it & 1u] = atomicAdd(recs.blocks, 1u);
-    __syncthreads();            // (the other slot is rewritten only after every thread has passed the next barrier)
-    const uint32_t blk = next_block[it & 1u];
+    uint32_t blk;
+    if (it < static_rounds) {
+        blk = it * gridDim.x + blockIdx.x;
+        if (threadIdx.x == 0 && it + 1 == static_rounds) ahead = static_rounds * gridDim.x + atomicAdd(recs.blocks, 1u);
+    } else {
+        if (threadIdx.x == 0) next_block[it & 1u] = ahead;
+        __syncthreads();        // (the other slot is rewritten only after every thread has passed the next barrier)
+        blk = next_block[it & 1u];
+        if (threadIdx.x == 0 && blk < nblocks) ahead = static_rounds * gridDim.x + atomicAdd(recs.blocks, 1u);
+    }
     if (blk >= nblocks) break;
     const uint32_t base = blk * WG;
     const uint32_t i = base + threadIdx.x;
@@ -816,7 +832,9 @@ __global__ __launch_bounds__(TPB) void k_td_play(LaneSet in, LaneSet out, const 
                 score += reward;
                 Packed after = pack_board(ch.after);
                 st_packed(prev_nxt, i, after);
+#ifndef G2048_EXP_NOORBIT
                 if constexpr (N >= 4) store_orbit_indices<N>(recs.oidx_nxt, B, i, after);
+#endif
                 old_label = c.value;
                 fl |= HAS_PREV;
                 moved = true;
@@ -1609,6 +1627,7 @@ struct g2048_ctx {
         double add_cost = 3.0, thr = 0.01, fixed_ratio = 0.25;
         int plan_feedback = 1, plan_xcd = 1, debug_plan = 0;
         unsigned play_wgs = 0;
+        uint32_t play_dynamic = 1;      // full rounds of k_td_play's lane blocks left to the counter (besides the last, partial one)
         uint32_t sort_every = 16;       // default of g2048_set_lane_sort for new contexts (G2048_SORT_EVERY); 0 = never
         uint32_t sort_min_batch = 1u << 17;     // smaller batches keep their lane order
         int mean_one_pass = 1;          // per-slot mean rule: counts packed beside the sums (0: always two accumulation passes)
@@ -1700,6 +1719,7 @@ void read_knobs(g2048_ctx* c) {
     if (const char* e = getenv("G2048_PLAN_XCD")) k.plan_xcd = atoi(e);
     if (getenv("G2048_DEBUG_PLAN")) k.debug_plan = 1;
     if (const char* e = getenv("G2048_PLAY_WGS")) k.play_wgs = (unsigned)atoi(e);
+    if (const char* e = getenv("G2048_PLAY_DYNAMIC")) k.play_dynamic = (uint32_t)atoi(e);
     if (const char* e = getenv("G2048_PLAY_HOT")) k.play_hot = atoi(e);
     if (const char* e = getenv("G2048_MEAN_ONE_PASS")) k.mean_one_pass = atoi(e);
     if (const char* e = getenv("G2048_SORT_EVERY")) k.sort_every = (uint32_t)atoi(e);
@@ -2262,6 +2282,12 @@ unsigned play_grid(g2048_ctx* c) {
     return need < c->play_wgs ? need : c->play_wgs;
 }
 
+// how many lane blocks every workgroup of k_td_play takes without asking the counter: all full rounds but `play_dynamic`
+uint32_t play_static_rounds(const g2048_ctx* c, unsigned grid, unsigned tpb) {
+    const uint32_t nblocks = (uint32_t)(((uint64_t)c->B + tpb - 1) / tpb), full = nblocks / grid;
+    return full > c->knob.play_dynamic ? full - c->knob.play_dynamic : 0u;
+}
+
 // the LDS hot set pays once a workgroup has enough lanes to amortise its 88 KB copy; n >= 4 only
 bool play_hot(const g2048_ctx* c) { return c->n >= 4 && c->knob.play_hot && c->B >= c->knob.play_hot_min; }
 
@@ -2298,7 +2324,8 @@ int launch_td_step(g2048_ctx* c, float alpha, hipEvent_t ev = nullptr, hipEvent_
         lout = c->alt;
     }
 #define G2048_PLAY(NN, TPB, HOT)                                                                                                      \
-    k_td_play<NN, TPB, HOT><<<play_grid<NN, TPB, HOT>(c), TPB, 0, c->stream>>>(lin, lout, perm, pn, B, c->w, alpha, recs, c->auto_reset, c->stats, c->log)
+    k_td_play<NN, TPB, HOT><<<play_grid<NN, TPB, HOT>(c), TPB, 0, c->stream>>>(lin, lout, perm, pn, B, c->w, alpha, recs, c->auto_reset, c->stats, c->log, \
+                                                                                play_static_rounds(c, play_grid<NN, TPB, HOT>(c), TPB))
     if (play_hot(c)) {
         switch (c->n) {
             case 4: G2048_PLAY(4, PLAY_HOT_WG, true); break;
