@@ -128,7 +128,13 @@ class QAgent:
 
     def __init__(self, name='agent', config_file=None, storage='s3', console='web', log_file=None, n=4, alpha=0.25,
                  decay=0.75, decay_step=10000, low_alpha_limit=0.01, with_weights=True, batch=1, seed=2048, device=0,
-                 rule=None):
+                 rule=None, dist=None, epoch=64, comm='native'):
+        """The reference's arguments (r_learning.py:90-91), then this build's: `batch` concurrent episodes on GPU `device`,
+        `rule` ('sum' = the reference's update, 'mean' = per-slot mean, the default for batch > 1), and for multi-GPU
+        training `dist` — an initialised torch.distributed module (one process per GPU: this agent is rank
+        dist.get_rank(), its `batch` lanes are the rank's shard of world * batch episodes, the table is replicated and the
+        accumulated weight deltas are all-reduced every `epoch` board-steps; comm = 'native' uses the C ABI's own RCCL
+        all-reduce, 'torch' the process group's)."""
         # identity and I/O (r_learning.py:93-99)
         self.name, self.file, self.game_file = name, name + '.pkl', 'best_of_' + name + '.pkl'
         self.s3, self.log_file = storage == 's3', log_file
@@ -147,6 +153,10 @@ class QAgent:
         self.next_decay = self.decay_step
         # device side
         self.batch, self.seed, self.device = int(batch), int(seed), int(device)
+        self._dist, self.epoch, self.comm = dist, int(epoch), comm
+        self.rank = dist.get_rank() if dist is not None else 0
+        self.world = dist.get_world_size() if dist is not None else 1
+        self._sync = None
         self.rule = rule or ('mean' if self.batch > 1 else 'sum')
         self._engine = self._solo = None
         self._pending_weights = None
@@ -163,7 +173,7 @@ class QAgent:
     def engine(self):
         """The training batch (owns the weight table)."""
         if self._engine is None:
-            self._engine = Engine(self.batch, n=self.n, seed=self.seed, device=self.device)
+            self._engine = Engine(self.batch, n=self.n, seed=self.seed, lane0=self.rank * self.batch, device=self.device)
             if self.batch > 1 and self.rule == 'mean':
                 self._engine.set_update_rule(1)
             if self._pending_weights is not None:
@@ -183,7 +193,12 @@ class QAgent:
 
     def init_weights(self):
         """U[0, 0.01) per slot (r_learning.py:136-149), drawn on the device."""
-        self.engine.init_weights(seed=np.random.randint(0, 2 ** 31), scale=0.01)
+        seed = int(np.random.randint(0, 2 ** 31))
+        if self.world > 1:                                    # every replica starts from rank 0's table (counter-based init)
+            box = [seed]
+            self._dist.broadcast_object_list(box, src=0)
+            seed = box[0]
+        self.engine.init_weights(seed=seed, scale=0.01)
         self.weight_signature = GROUPS[self.n]
 
     @property
@@ -220,7 +235,7 @@ class QAgent:
     # ---- persistence (r_learning.py:166-200): parameters and weights are stored separately in 's3' mode
 
     def __getstate__(self):
-        state = {k: v for k, v in self.__dict__.items() if k not in ('_engine', '_solo', '_pending_weights', 'print')}
+        state = {k: v for k, v in self.__dict__.items() if k not in ('_engine', '_solo', '_pending_weights', 'print', '_dist', '_sync')}
         state['weights'] = self.list_to_np() if (self._engine is not None or self._pending_weights is not None) else None
         return state
 
@@ -231,7 +246,10 @@ class QAgent:
         self.__dict__.setdefault('seed', 2048)
         self.__dict__.setdefault('device', 0)
         self.__dict__.setdefault('rule', 'mean' if self.batch > 1 else 'sum')
-        self._engine = self._solo = self._pending_weights = None
+        self.__dict__.update(rank=0, world=1)                 # a loaded agent is single-process until attach_dist
+        self.__dict__.setdefault('epoch', 64)
+        self.__dict__.setdefault('comm', 'native')
+        self._engine = self._solo = self._pending_weights = self._dist = self._sync = None
         self.print = print
         self.features = QAgent.feature_functions[self.n]
         if groups is not None:
@@ -242,7 +260,7 @@ class QAgent:
             nps = self.list_to_np()
             params = QAgent(name=self.name, with_weights=False)
             for key, value in self.__dict__.items():
-                if key not in ('_engine', '_solo', '_pending_weights'):
+                if key not in ('_engine', '_solo', '_pending_weights', '_dist', '_sync'):
                     setattr(params, key, value)
             save_s3(params, 'a/' + self.file)
             save_s3(nps, 'weights/' + self.file)
@@ -385,9 +403,43 @@ class QAgent:
             self.save_agent()
             self.print(f'{self.name} saved at step {self.step} in {self.file}\n------------------------\n')
 
+    def attach_dist(self, dist, device=None):
+        """Make a loaded (or single-process) agent one rank of a multi-GPU job; call before the engine exists."""
+        assert self._engine is None, 'attach_dist before the first use of the device'
+        self._dist, self.rank, self.world = dist, dist.get_rank(), dist.get_world_size()
+        if device is not None:
+            self.device = int(device)
+
+    def _epoch_sync(self):
+        """The per-epoch exchange of the accumulated weight deltas (2048_amd/parallel.py), built on first use."""
+        if self.world == 1:
+            return None
+        if self._sync is None:
+            from . import parallel
+            eng, sync = self.engine, None
+            if self.comm == 'native':
+                import torch
+                ok = 1
+                try:
+                    sync = parallel.NativeSync(eng, self.rank, self.world, parallel.broadcast_id_torch(self._dist))
+                except Exception as e:                         # (every rank must agree before falling back)
+                    self.print(f'rank {self.rank}: native RCCL path unavailable ({e!r}); using torch.distributed')
+                    ok = 0
+                flag = torch.tensor([ok], dtype=torch.int32, device=f'cuda:{self.device}' if self._dist.get_backend() == 'nccl' else 'cpu')
+                self._dist.all_reduce(flag, op=self._dist.ReduceOp.MIN)
+                if int(flag.item()) == 0:
+                    if sync is not None:
+                        sync.close()
+                    sync = None
+            if sync is None:
+                sync = parallel.DeltaSync(eng, self._dist, rule=self.rule)
+            sync.begin()
+            self._sync = sync
+        return self._sync
+
     def device_alpha(self, lanes=None):
         """The batch rule: alpha for g2048_td_steps when `lanes` episodes learn concurrently."""
-        lanes = self.batch if lanes is None else lanes
+        lanes = self.batch * self.world if lanes is None else lanes
         if lanes == 1 or self.rule == 'mean':
             return self.alpha
         return self.alpha * self.num_feat / (8.0 * lanes)
@@ -434,16 +486,30 @@ class QAgent:
         WATCHED_LANES lanes, whose moves and tiles the device records."""
         eng = self.engine
         eng.set_auto_reset(True)
+        sync = self._epoch_sync()
+        chief = self.rank == 0
+        if not chief:
+            saving = False                                    # rank 0 prints, keeps the best game and saves
+            self.print = lambda *a, **k: None
+        if sync is not None:
+            from . import parallel
+            chunk = self.epoch
+
+            def job_stats():                                  # the counters of all ranks: every rank takes the same decisions
+                return parallel.reduce_stats(eng.stats(), self._dist, device=f'cuda:{self.device}' if self._dist.get_backend() == 'nccl' else 'cpu')
+        else:
+            job_stats = eng.stats
         watched = min(self.batch, self.WATCHED_LANES)
         eng.log_enable(watched, self.LOG_CAPACITY)
         seen = np.zeros(watched, np.uint32)
         if stopper:
             parent, this_thread = stopper['parent'], stopper['a']
         global_start = start = benchmark_time = time.time()
-        self.print(f'Agent {self.name} training session started, current step = {self.step}, {self.batch} concurrent episodes')
+        self.print(f'Agent {self.name} training session started, current step = {self.step}, {self.batch} concurrent episodes'
+                   + (f' on each of {self.world} GPUs, weight deltas exchanged every {chunk} steps' if sync is not None else ''))
         eng.stats_reset()
         base = self.step
-        last = eng.stats()
+        last = job_stats()
         mark100, mark1000 = dict(last), dict(last)
         next100 = (self.step // 100 + 1) * 100
         next1000 = (self.step // 1000 + 1) * 1000
@@ -458,7 +524,9 @@ class QAgent:
             if self.step > self.next_decay and self.alpha > self.low_alpha_limit:
                 self.decay_alpha()
             eng.td_steps(self.device_alpha(), chunk)
-            st = eng.stats()
+            if sync is not None:
+                sync.all_reduce()
+            st = job_stats()
             self.step = base + st['episodes']
             self.top_score = max(self.top_score, st['best_score'])
             self._collect_best_games(eng, seen, saving)

@@ -9,12 +9,14 @@ import sys
 
 import numpy as np
 import pytest
+import torch  # noqa: F401  (before lib2048_hip.so: PyTorch brings its own HIP runtime, which must come up first in a process that uses both)
 
 from tests import helpers
 from tests.golden import formulas
 
 pytestmark = pytest.mark.gpu
 pkg = importlib.import_module('2048_amd')
+importlib.import_module('2048_amd.engine')
 parallel = importlib.import_module('2048_amd.parallel')
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -142,3 +144,30 @@ def test_bench_self_launch_two_ranks_gloo():
     assert line['n_gpus'] == 2 and line['steps'] == 12 and line['warmup'] == 3 and line['scaling'] == 'weak'
     assert line['value'] > 0 and 'all-reduce every 5 steps' in line['config']['parallelism']
     assert line['roofline']['frac'] <= 1.0
+
+
+def test_qagent_train_run_two_ranks(tmp_path):
+    """QAgent.train_run as a two-rank job (both ranks on this box's one GPU, gloo carrying the control traffic and the
+    deltas): the ranks play different shards, exchange their accumulated deltas every epoch and stay identical replicas
+    with identical schedules; rank 0 reports for the job."""
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    dump = str(tmp_path / 'rank')
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'tools', 'train_multi.py'), '--n', '4', '--batch', '8192', '--episodes', '30000',
+                                       '--epoch', '32', '--backend', 'gloo', '--comm', 'torch', '--dump', dump], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs[0][1][-1500:] + outs[1][1][-1500:]
+    a, b = (np.load(f'{dump}.{r}.npz') for r in range(2))
+    assert int(a['step']) == int(b['step']) >= 30000 and float(a['alpha']) == float(b['alpha']) and int(a['top_tile']) == int(b['top_tile'])
+    assert np.array_equal(a['history'], b['history']) and len(a['history']) > 5
+    assert np.array_equal(a['w_head'], b['w_head']) and np.array_equal(a['w_tail'], b['w_tail']) and float(a['wsum']) == float(b['wsum'])
+    assert int(a['reduces']) > 3 and str(a['sync']) == 'DeltaSync'
+    assert 'training session started' in outs[0][0] and 'on each of 2 GPUs' in outs[0][0] and 'training session started' not in outs[1][0]
+    assert a['history'][-1] > a['history'][0]                 # and it learns
