@@ -798,7 +798,13 @@ __global__ __launch_bounds__(TPB) void k_td_play(LaneSet in, LaneSet out, const 
     float dw_big = 0.0f;            // largest |dw| this lane emits
     if (i < B) {
         const uint32_t src = perm ? perm[i] : i;
+        // the whole lane state is requested at once: loading the flags first and the rest behind the DONE test would put two
+        // memory round trips in front of every block
         uint8_t fl = in.flags[src];
+        Board b = ld_board(in.boards, src);
+        Rng g = ld_rng(in.rng, src);
+        int32_t score = in.scores[src];
+        float old_label = in.label[src];
         uint32_t lid = i;
         if (perm || lg.lanes) lid = in.lane_id[src];
         if (perm) out.lane_id[i] = lid;
@@ -806,18 +812,14 @@ __global__ __launch_bounds__(TPB) void k_td_play(LaneSet in, LaneSet out, const 
         uint32_t lm = 0;        // what this lane did: bits 0-1 direction, 2 moved, 4-7 new tile's cell, 8-9 new tile, 10 spawned, 11 game ended
         if (fl & DONE) {
             if (perm) {         // a finished lane moves with the others
-                out.boards[i] = in.boards[src];
-                out.rng[i] = in.rng[src];
-                out.scores[i] = in.scores[src];
-                out.label[i] = in.label[src];
+                st_board(out.boards, i, b);
+                st_rng(out.rng, i, g);
+                out.scores[i] = score;
+                out.label[i] = old_label;
                 out.flags[i] = fl;
                 prev_nxt[i] = recs.state1[src];
             }
         } else {
-            Board b = ld_board(in.boards, src);
-            Rng g = ld_rng(in.rng, src);
-            int32_t score = in.scores[src];
-            float old_label = in.label[src];
             Moves4 mv = all_moves(b);
             Choice c;
             if constexpr (HOT)
@@ -949,6 +951,7 @@ struct Slice {
     uint64_t fb_mask;
     uint32_t cshift;        // log2 of the slots per chunk of this orbit table (OWN_SLOTS, or OWN_SLOTS / 2 for the fixed-point orbits)
     uint32_t fixed;         // 1: this workgroup sums in 64-bit fixed point (own_fixed, or every variant under the one-pass mean rule)
+    uint32_t xcd;           // 1: XCD-resident plan — part = x * (nparts / 8) + j scans the record blocks b = x + 8 * (j + (nparts / 8) * t)
 };
 
 // Symmetry orbits (n >= 4).  QAgent.update adds dw at f_i(g.x) for all 8 images g (r_learning.py:207-214).  Features
@@ -1115,9 +1118,12 @@ __device__ __forceinline__ void own_run(float* acc, const Slice& s, const TdRecs
         const uint32_t lo_rel = s.tlo - s.orb_tlo;
         // a part takes every nparts-th block of records, not one contiguous range: the lanes may be ordered by board
         // pattern (LaneSort), and neighbouring records then hit the same few slots
+        // (XCD-resident plan: the blocks b = x (mod 8) belong to XCD x for EVERY chunk, so that one L2 serves all their scans)
         constexpr uint32_t BLK = OWN_WG * U;
         const uint32_t nblk = (B + BLK - 1) / BLK, end = B;
-        for (uint32_t blk = s.part; blk < nblk; blk += s.nparts) {
+        const uint32_t per_xcd = s.xcd ? s.nparts >> 3 : 0u;
+        const uint32_t first = s.xcd ? s.part / per_xcd + 8u * (s.part % per_xcd) : s.part, stride = s.xcd ? 8u * per_xcd : s.nparts;
+        for (uint32_t blk = first; blk < nblk; blk += stride) {
             const uint32_t base0 = blk * BLK;
             uint32_t idx[U][NI];
             float dw[U];
@@ -2126,7 +2132,7 @@ int build_slices(g2048_ctx* c) {
     auto slice_of = [&](size_t k, uint32_t p, uint32_t np) {
         return Slice{chunks[k].variant, chunks[k].tlo, chunks[k].size, chunks[k].dlo, p, np, (uint32_t)k,
                      chunks[k].orb_tlo, chunks[k].orb_dlo, chunks[k].chunk0, duty[k], chunks[k].size >= OWN_SLOTS ? 15u : 14u,
-                     chunk_fixed(c, (int)chunks[k].variant) ? 1u : 0u};
+                     chunk_fixed(c, (int)chunks[k].variant) ? 1u : 0u, 0u};
     };
     // 0: flat plan; 1 (default where it applies): XCD-resident scan.  (Cutting the chunks into pieces packed onto the 32
     // workgroups of an XCD, a workgroup running its pieces one after the other, was tried: 0.296 -> 0.311 ms per step.)
@@ -2153,7 +2159,11 @@ int build_slices(g2048_ctx* c) {
         });
         for (const auto& kj : per_xcd)
             for (uint32_t x = 0; x < XCDS; ++x)
-                v.push_back(slice_of(kj.first, x * parts[kj.first] + kj.second, XCDS * parts[kj.first]));
+            {
+                Slice sl = slice_of(kj.first, x * parts[kj.first] + kj.second, XCDS * parts[kj.first]);
+                sl.xcd = 1u;
+                v.push_back(sl);
+            }
     } else {
         // one-pass mean rule: a workgroup's count field must leave the sums enough bits (k_td_update_owner), so no
         // workgroup scans more than 2^21 / 4 records
