@@ -748,6 +748,19 @@ __device__ __forceinline__ void log_step(const GameLog& lg, uint32_t i, uint32_t
     m[1] = cnt;
 }
 
+#ifdef G2048_EXP_PHASES      // (experiment build: where a wave of k_td_play spends its time; tools/exp/phases.py)
+__device__ unsigned long long g_phase_ticks[8192 * 4 * 8];    // [workgroup][wave][phase], summed by the host
+__device__ unsigned long long g_wg_span[2 * 8192];
+#define PHASE_STAMP(k)                                          \
+    do {                                                        \
+        const unsigned long long now_ = wall_clock64();         \
+        phase_acc_[k] += now_ - phase_t_;                       \
+        phase_t_ = now_;                                        \
+    } while (0)
+#else
+#define PHASE_STAMP(k) do { } while (0)
+#endif
+
 // Step part 1 — the body of `while not game.game_over` in QAgent.episode (r_learning.py:228-246) for every live
 // lane, all reading the same table.  `prev` is double-buffered: prev_cur holds `state`, prev_nxt receives this
 // step's afterstate, so the main record needs no copy.
@@ -775,6 +788,11 @@ __global__ __launch_bounds__(TPB) void k_td_play(LaneSet in, LaneSet out, const 
     // issued before the block's loads and stores, so that waiting for it at the next hand-out does not wait for those
     // stores (vmcnt retires in order).  Measured at 2^20 lanes, n = 5: all rounds from the counter 0.213-0.230 ms, all but
     // one static 0.194-0.218 ms, all static 0.230-0.242 ms (gpurun_out r02p).
+#ifdef G2048_EXP_PHASES
+    unsigned long long phase_t_ = wall_clock64();
+    unsigned long long phase_acc_[8] = {};
+    if (threadIdx.x == 0 && blockIdx.x < 8192) g_wg_span[2 * blockIdx.x] = phase_t_;
+#endif
     __shared__ uint32_t next_block[2];
     const uint32_t nblocks = (B + WG - 1) / WG;
     uint32_t ahead = 0;
@@ -791,6 +809,7 @@ __global__ __launch_bounds__(TPB) void k_td_play(LaneSet in, LaneSet out, const 
         if (threadIdx.x == 0 && blk < nblocks) ahead = static_rounds * gridDim.x + atomicAdd(recs.blocks, 1u);
     }
     if (blk >= nblocks) break;
+    PHASE_STAMP(0);             // block hand-out
     const uint32_t base = blk * WG;
     const uint32_t i = base + threadIdx.x;
     bool moved = false;
@@ -821,11 +840,13 @@ __global__ __launch_bounds__(TPB) void k_td_play(LaneSet in, LaneSet out, const 
             }
         } else {
             Moves4 mv = all_moves(b);
+            PHASE_STAMP(1);     // state loads + moves
             Choice c;
             if constexpr (HOT)
                 c = choose_hot<N>(w, hot, mv);
             else
                 c = choose<N>(w, mv);
+            PHASE_STAMP(2);     // features, gathers, sums, select
             bool over, overflow = false;
             if (c.action >= 0) {
                 Moved ch = pick(mv, (uint32_t)c.action);
@@ -878,6 +899,7 @@ __global__ __launch_bounds__(TPB) void k_td_play(LaneSet in, LaneSet out, const 
                     }
                 }
             }
+            PHASE_STAMP(3);     // pick, spawn, terminal test, orbit indices
             const int32_t final_score = score;
             if (over) {
                 lm |= 1u << 11;
@@ -910,9 +932,16 @@ __global__ __launch_bounds__(TPB) void k_td_play(LaneSet in, LaneSet out, const 
     }
     if (dw_big > 0.0f) atomicMax(&ws.dw_max_bits, __float_as_uint(dw_big));
     count_moves(&ws, moved ? 1u : 0u, ndirs);
+    PHASE_STAMP(4);             // reset, stores (issued), statistics
     }
     wg_stats_flush(&ws, stats);
     if (threadIdx.x == 0 && ws.dw_max_bits) atomicMax(recs.dwmax, ws.dw_max_bits);
+#ifdef G2048_EXP_PHASES
+    PHASE_STAMP(5);             // leaving the loop, statistics flush
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 8192 && threadIdx.x < 256)
+        for (int k = 0; k < 8; ++k) g_phase_ticks[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + k] += phase_acc_[k];
+    if (threadIdx.x == 0 && blockIdx.x < 8192) g_wg_span[2 * blockIdx.x + 1] = wall_clock64();
+#endif
 }
 
 // Step part 2, global-atomics form — QAgent.update for every record: thread t adds image (t & 7) of record (t >> 3);
@@ -1441,6 +1470,215 @@ __global__ __launch_bounds__(OWN_WG) void k_td_update_tail(float* D, TdRecs recs
         if (keys[j] != TAIL_EMPTY && vals[j] != 0.0f) __hip_atomic_fetch_add(&D[keys[j]], vals[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// ------------------------------------------------------------------------------------------------ n = 6: binned update of the f_6 orbits
+// The two f_6 orbit tables (2 x 14^6 = 15 059 072 slots of D behind the LDS-owned ones) take 8 + 4 adds per record.
+// k_td_update_tail sends them to memory as scattered atomics (~16 G/s: 0.75 ms per step of 2^20 lanes).  Here they are
+// first BINNED by table chunk and then summed by a workgroup that owns the chunk in LDS, like the other orbits:
+//   k_hex_count    every record's 12 chunk numbers -> chunk histogram (LDS per workgroup, then global)
+//   k_hex_plan     exclusive scan -> where each chunk's (slot, dw) pairs start; a work list of (chunk, part) for the owners
+//   k_hex_scatter  the same traversal; a workgroup reserves room for its tile's pairs with ONE atomic per chunk it touches,
+//                  places each pair with an LDS counter, and writes (slot, dw) — 8 B — into the chunk's run
+//   k_hex_owner    one workgroup per (chunk, part): pairs -> 64-bit fixed-point LDS sums (counts packed under them for the
+//                  mean rule) -> D (one writer per slot unless the chunk was split)
+// k_apply_orbits then moves D into the twelve member tables as before.
+constexpr uint32_t HEX_SLOTS = 2u * HEX_SIZE;               // both orbit tables, contiguous in D
+constexpr uint32_t HEX_CHUNK = 16384u;                      // slots per chunk: 128 KB of 64-bit LDS sums
+constexpr uint32_t HEX_BINS = (HEX_SLOTS + HEX_CHUNK - 1) / HEX_CHUNK;     // 920
+constexpr uint32_t HEX_PART_PAIRS = 1u << 16;               // an owner workgroup takes at most this many pairs
+constexpr uint32_t HEX_MAX_WORK = 4096;
+
+struct HexWork {        // one owner workgroup
+    uint32_t bin, first, count, split;      // pairs [first, first + count) of chunk `bin`; split: the chunk has several workgroups
+};
+
+struct HexBufs {
+    uint32_t* count;        // [HEX_BINS] pairs per chunk (this step)
+    uint32_t* base;         // [HEX_BINS + 1] first pair of each chunk
+    uint32_t* cursor;       // [HEX_BINS] next free pair of each chunk during the scatter
+    uint2* pairs;           // (slot in the two tables, dw bits)
+    HexWork* work;          // [HEX_MAX_WORK]
+    uint32_t* nwork;
+};
+
+// the 16 slots (relative to the first f_6 orbit table) one record adds to: all 8 images of the corner-block representative
+// and of the middle-block representative.  (The middle block is fixed by the left-right mirror, and k_td_update_tail visits
+// one image per coset and lets k_apply_orbits pair k with sigma(k); here the pairs are cheap and the apply step stays local
+// to a chunk, so all 8 images are visited and D is the orbit table itself.)
+constexpr int HEX_PAIRS = 16;
+template <int N>
+__device__ __forceinline__ void hex_record_slots(const Packed& p, uint32_t (&out)[HEX_PAIRS]) {
+    constexpr int F = Shape<N>::F;
+#pragma unroll
+    for (uint32_t g = 0; g < 8; ++g) {
+        uint32_t s[F];
+        feature_slots<N>(d4_image(p, g), s);
+        out[g] = s[21] - feature_offset(N, 21);
+        out[8 + g] = HEX_SIZE + (s[22] - feature_offset(N, 22));
+    }
+}
+
+// record r of the step: main records 0 .. B-1 (dw1 != 0), then the terminal queue
+__device__ __forceinline__ bool hex_load_record(const TdRecs& recs, uint32_t B, uint32_t r, uint32_t total, Packed& p, float& dw) {
+    if (r >= total) return false;
+    if (r < B) {
+        dw = recs.dw1[r];
+        if (dw == 0.0f) return false;
+        p = ld_packed(recs.state1, r);
+    } else {
+        dw = recs.qdw[r - B];
+        p = ld_packed(recs.qstate, r - B);
+    }
+    return true;
+}
+
+template <int N>
+__global__ __launch_bounds__(OWN_WG) void k_hex_count(TdRecs recs, uint32_t B, HexBufs hb) {
+    __shared__ uint32_t hist[HEX_BINS];
+    for (uint32_t j = threadIdx.x; j < HEX_BINS; j += OWN_WG) hist[j] = 0;
+    __syncthreads();
+    const uint32_t total = B + *recs.qcount;
+    for (uint32_t r = blockIdx.x * OWN_WG + threadIdx.x; r < total; r += gridDim.x * OWN_WG) {
+        Packed p;
+        float dw;
+        if (!hex_load_record(recs, B, r, total, p, dw)) continue;
+        uint32_t s[HEX_PAIRS];
+        hex_record_slots<N>(p, s);
+#pragma unroll
+        for (int j = 0; j < HEX_PAIRS; ++j) atomicAdd(&hist[s[j] / HEX_CHUNK], 1u);
+    }
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < HEX_BINS; j += OWN_WG)
+        if (hist[j]) atomicAdd(&hb.count[j], hist[j]);
+}
+
+// one workgroup: scan the histogram, cut busy chunks into parts, clear the counters for the next step
+__global__ __launch_bounds__(OWN_WG) void k_hex_plan(HexBufs hb) {
+    __shared__ uint32_t pre[OWN_WG], wpre[OWN_WG];
+    const uint32_t j = threadIdx.x;
+    const uint32_t c = j < HEX_BINS ? hb.count[j] : 0u;
+    const uint32_t parts = (c + HEX_PART_PAIRS - 1) / HEX_PART_PAIRS;
+    pre[j] = c;
+    wpre[j] = parts;
+    __syncthreads();
+    for (uint32_t off = 1; off < OWN_WG; off <<= 1) {       // inclusive scans of the pair counts and of the part counts
+        const uint32_t a = j >= off ? pre[j - off] : 0u, b = j >= off ? wpre[j - off] : 0u;
+        __syncthreads();
+        pre[j] += a;
+        wpre[j] += b;
+        __syncthreads();
+    }
+    const uint32_t first = pre[j] - c, wfirst = wpre[j] - parts;
+    if (j < HEX_BINS) {
+        hb.base[j] = first;
+        hb.cursor[j] = first;
+        hb.count[j] = 0;
+        for (uint32_t k = 0; k < parts && wfirst + k < HEX_MAX_WORK; ++k) {
+            const uint32_t lo = (uint32_t)((uint64_t)c * k / parts), hi = (uint32_t)((uint64_t)c * (k + 1) / parts);
+            hb.work[wfirst + k] = HexWork{j, first + lo, hi - lo, parts > 1 ? 1u : 0u};
+        }
+    }
+    if (j == OWN_WG - 1) {
+        hb.base[HEX_BINS] = pre[j];
+        *hb.nwork = wpre[j] < HEX_MAX_WORK ? wpre[j] : HEX_MAX_WORK;
+    }
+}
+
+template <int N>
+__global__ __launch_bounds__(OWN_WG) void k_hex_scatter(TdRecs recs, uint32_t B, HexBufs hb) {
+    __shared__ uint32_t hist[HEX_BINS], lbase[HEX_BINS];
+    const uint32_t total = B + *recs.qcount;
+    const uint32_t ntiles = (total + OWN_WG - 1) / OWN_WG;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {        // (uniform trip count: barriers inside)
+        for (uint32_t j = threadIdx.x; j < HEX_BINS; j += OWN_WG) hist[j] = 0;
+        __syncthreads();
+        Packed p;
+        float dw = 0.0f;
+        uint32_t s[HEX_PAIRS];
+        const bool ok = hex_load_record(recs, B, tile * OWN_WG + threadIdx.x, total, p, dw);
+        if (ok) {
+            hex_record_slots<N>(p, s);
+#pragma unroll
+            for (int j = 0; j < HEX_PAIRS; ++j) atomicAdd(&hist[s[j] / HEX_CHUNK], 1u);
+        }
+        __syncthreads();
+        for (uint32_t j = threadIdx.x; j < HEX_BINS; j += OWN_WG) {
+            const uint32_t h = hist[j];
+            lbase[j] = h ? atomicAdd(&hb.cursor[j], h) : 0u;       // room for this tile's pairs in chunk j
+            hist[j] = 0;                                            // becomes the tile's running count
+        }
+        __syncthreads();
+        if (ok) {
+            const uint32_t bits = recs.unit ? __float_as_uint(1.0f) : __float_as_uint(dw);
+#pragma unroll
+            for (int j = 0; j < HEX_PAIRS; ++j) {
+                const uint32_t bin = s[j] / HEX_CHUNK;
+                hb.pairs[lbase[bin] + atomicAdd(&hist[bin], 1u)] = make_uint2(s[j], bits);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// D (and Dc: the add counts, when the mean rule runs in one pass) += the sums of one chunk part
+__global__ __launch_bounds__(OWN_WG) void k_hex_owner(float* D, float* Dc, const TdRecs recs, HexBufs hb) {
+    __shared__ unsigned long long acc[HEX_CHUNK];
+    if (blockIdx.x >= *hb.nwork) return;
+    const HexWork wk = hb.work[blockIdx.x];
+    // fixed-point scale as in k_td_update_owner: |sum| < count x 2^(e + S) must fit beside the count bits
+    const float big = recs.unit ? 1.0f : __uint_as_float(*recs.dwmax);
+    const int e = big > 0.0f ? ilogbf(big) + 1 : 0;
+    const int add_bits = 32 - __clz((int)(wk.count | 1u));
+    const uint32_t cbits = Dc ? (uint32_t)add_bits + 1u : 0u;
+    int S = 38 - e;
+    if (S > 61 - (int)cbits - e - add_bits) S = 61 - (int)cbits - e - add_bits;
+    S = S > 100 ? 100 : (S < -60 ? -60 : S);
+    const double scale = (double)ldexpf(1.0f, S), inv_scale = (double)ldexpf(1.0f, -S);
+    for (uint32_t j = threadIdx.x; j < HEX_CHUNK; j += OWN_WG) acc[j] = 0ull;
+    __syncthreads();
+    const uint32_t lo = wk.bin * HEX_CHUNK;
+    for (uint32_t k = threadIdx.x; k < wk.count; k += OWN_WG) {
+        const uint2 pr = hb.pairs[wk.first + k];
+        atomicAdd(&acc[pr.x - lo], packed_add(__uint_as_float(pr.y), scale, cbits));
+    }
+    __syncthreads();
+    const unsigned long long cmask = (1ull << cbits) - 1ull;
+    for (uint32_t j = threadIdx.x; j < HEX_CHUNK; j += OWN_WG) {
+        const unsigned long long word = acc[j];
+        if (!word || lo + j >= HEX_SLOTS) continue;
+        const unsigned long long n = word & cmask;
+        const float v = (float)((double)((long long)(word - n) >> cbits) * inv_scale), cnt = (float)n;
+        if (wk.split) {
+            if (v != 0.0f) __hip_atomic_fetch_add(&D[lo + j], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (cnt != 0.0f) __hip_atomic_fetch_add(&Dc[lo + j], cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (v != 0.0f) D[lo + j] += v;
+            if (cnt != 0.0f) Dc[lo + j] += cnt;
+        }
+    }
+}
+
+// D -> the member tables of the two f_6 orbits, chunk by chunk, only for the chunks that received pairs this step (a
+// step touches a few hundred of the 920); clears what it read.  Sc / Cc non-null: per-slot mean rule (v = S / C).
+__global__ __launch_bounds__(WG) void k_hex_apply(float* w, float* dacc, float* Dh, float* Ch, HexBufs hb, OrbitInfo oa, OrbitInfo ob) {
+    const uint32_t K = blockIdx.x * WG + threadIdx.x;           // (a workgroup's 256 slots lie in one chunk)
+    const uint32_t bin = K / HEX_CHUNK;
+    if (K >= HEX_SLOTS || hb.base[bin + 1] == hb.base[bin]) return;
+    float v = Dh[K];
+    if (Ch) {
+        const float cnt = Ch[K];
+        if (cnt == 0.0f) return;
+        v /= cnt;
+        Ch[K] = 0.0f;
+    } else if (v == 0.0f) {
+        return;
+    }
+    Dh[K] = 0.0f;
+    if (K < HEX_SIZE)
+        add_to_members(w, dacc, oa, K, v);
+    else
+        add_to_members(w, dacc, ob, K - HEX_SIZE, v);
+}
+
 // ------------------------------------------------------------------------------------------------ lane order (LaneSort)
 // k_td_play is bound by L1 misses of its table gathers: a CU's 32 KB L1 sees ~4 000 unrelated boards per launch.  Which
 // cache lines a board's COLD tuples touch is decided by where its big tiles sit (the small ones come and go every move),
@@ -1605,6 +1843,7 @@ struct g2048_ctx {
     bool tracking = false;
     float* pack = nullptr;
     size_t pack_count = 0;
+    HexBufs hex = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // n = 6: binned update of the f_6 orbits (k_hex_*)
     void* comm = nullptr;               // ncclComm_t of g2048_comm_init
     int comm_rank = 0, comm_ranks = 1;
     Stats* stats = nullptr;
@@ -1636,6 +1875,7 @@ struct g2048_ctx {
         uint32_t play_dynamic = 1;      // full rounds of k_td_play's lane blocks left to the counter (besides the last, partial one)
         uint32_t sort_every = 16;       // default of g2048_set_lane_sort for new contexts (G2048_SORT_EVERY); 0 = never
         uint32_t sort_min_batch = 1u << 17;     // smaller batches keep their lane order
+        int hex_bins = 1;               // n = 6: f_6 orbits through k_hex_* (0: k_td_update_tail's scattered atomics)
         int mean_one_pass = 1;          // per-slot mean rule: counts packed beside the sums (0: always two accumulation passes)
         int play_hot = 0;               // 1: k_td_play reads the hot four-cell tuples from an LDS copy (n >= 4, big batches); measured, not faster
         uint32_t play_hot_min = 1u << 16;   // smallest batch that takes that path (a workgroup copies 88 KB per launch)
@@ -1728,6 +1968,7 @@ void read_knobs(g2048_ctx* c) {
     if (const char* e = getenv("G2048_PLAY_DYNAMIC")) k.play_dynamic = (uint32_t)atoi(e);
     if (const char* e = getenv("G2048_PLAY_HOT")) k.play_hot = atoi(e);
     if (const char* e = getenv("G2048_MEAN_ONE_PASS")) k.mean_one_pass = atoi(e);
+    if (const char* e = getenv("G2048_HEX_BINS")) k.hex_bins = atoi(e);
     if (const char* e = getenv("G2048_SORT_EVERY")) k.sort_every = (uint32_t)atoi(e);
     if (const char* e = getenv("G2048_SORT_MIN")) k.sort_min_batch = (uint32_t)atoi(e);
     if (const char* e = getenv("G2048_PLAY_HOT_MIN")) k.play_hot_min = (uint32_t)atoi(e);
@@ -2042,6 +2283,13 @@ int build_slices(g2048_ctx* c) {
             HIP_TRY(c, hipMemset(c->D, 0, (size_t)c->orbits.total * 4));
             if ((rc = dalloc(c, &c->D2, c->owned_total))) return rc;
             HIP_TRY(c, hipMemset(c->D2, 0, (size_t)c->owned_total * 4));
+            if (c->n == 6 && c->B <= (1u << 23)) {       // binned update of the f_6 orbits: 16 pairs per record, main + terminal
+                if ((rc = dalloc(c, &c->hex.count, HEX_BINS)) || (rc = dalloc(c, &c->hex.base, HEX_BINS + 1)) ||
+                    (rc = dalloc(c, &c->hex.cursor, HEX_BINS)) || (rc = dalloc(c, &c->hex.pairs, (size_t)2 * HEX_PAIRS * c->B)) ||
+                    (rc = dalloc(c, &c->hex.work, HEX_MAX_WORK)) || (rc = dalloc(c, &c->hex.nwork, 1)))
+                    return rc;
+                HIP_TRY(c, hipMemset(c->hex.count, 0, HEX_BINS * 4));
+            }
         }
         if (int rc = dalloc(c, &c->slices, MAX_SLICES)) return rc;
         if (int rc = dalloc(c, &c->statbuf, STAT_BYTES)) return rc;
@@ -2371,6 +2619,7 @@ int launch_td_step(g2048_ctx* c, float alpha, hipEvent_t ev = nullptr, hipEvent_
         // (the planner keeps the record ranges that short).
         // Beyond that (and for the n = 6 tail kernel) the counts take a second run of the same accumulation with dw = 1.
         bool one_pass = false;
+        const bool hex_binned = c->n == 6 && c->knob.hex_bins && c->hex.pairs;
         if (c->update_rule == 1) {
             uint32_t min_parts = ~0u;
             for (const Slice& sl : c->plan) min_parts = sl.nparts < min_parts ? sl.nparts : min_parts;
@@ -2379,7 +2628,7 @@ int launch_td_step(g2048_ctx* c, float alpha, hipEvent_t ev = nullptr, hipEvent_
             TdRecs ones = recs;
             ones.unit = 1;
             if (!one_pass) BY_N(c, (k_td_update_owner<N><<<c->n_slices, OWN_WG, 0, c->stream>>>(Ccur, nullptr, ones, B, c->slices, c->hits, c->wg_clock)));
-            if (c->n == 6) k_td_update_tail<6><<<tail_grid, OWN_WG, 0, c->stream>>>(c->Dcnt, ones, B, c->orbits.o[6].base, c->orbits.o[7].base);
+            if (c->n == 6 && !hex_binned) k_td_update_tail<6><<<tail_grid, OWN_WG, 0, c->stream>>>(c->Dcnt, ones, B, c->orbits.o[6].base, c->orbits.o[7].base);
         }
         // n = 2, 3: the workgroups add straight into the table, unless the sums are needed apart (mean rule, delta tracking)
         const bool flat_apart = c->n < 4 && (c->update_rule == 1 || dacc);
@@ -2387,18 +2636,32 @@ int launch_td_step(g2048_ctx* c, float alpha, hipEvent_t ev = nullptr, hipEvent_
         float* cdst = one_pass ? (c->n >= 4 ? Ccur : c->Dcnt) : nullptr;
         BY_N(c, (k_td_update_owner<N><<<c->n_slices, OWN_WG, 0, c->stream>>>(dst, cdst, recs, B, c->slices, c->hits, c->wg_clock)));
         if (ev_owner) (void)hipEventRecord(ev_owner, c->stream);
-        if (c->n == 6) k_td_update_tail<6><<<tail_grid, OWN_WG, 0, c->stream>>>(c->D, recs, B, c->orbits.o[6].base, c->orbits.o[7].base);
+        if (hex_binned) {           // the f_6 orbits: bin the (slot, dw) pairs by table chunk, then LDS owners (k_hex_*)
+            const uint32_t hb = c->orbits.o[6].base;
+            const unsigned owners = (unsigned)std::min<uint64_t>(HEX_MAX_WORK, HEX_BINS + (uint64_t)2 * HEX_PAIRS * B / HEX_PART_PAIRS + 1);
+            k_hex_count<6><<<512, OWN_WG, 0, c->stream>>>(recs, B, c->hex);
+            k_hex_plan<<<1, OWN_WG, 0, c->stream>>>(c->hex);
+            k_hex_scatter<6><<<1024, OWN_WG, 0, c->stream>>>(recs, B, c->hex);
+            k_hex_owner<<<owners, OWN_WG, 0, c->stream>>>(c->D + hb, c->update_rule == 1 ? c->Dcnt + hb : nullptr, recs, c->hex);
+        } else if (c->n == 6) {
+            k_td_update_tail<6><<<tail_grid, OWN_WG, 0, c->stream>>>(c->D, recs, B, c->orbits.o[6].base, c->orbits.o[7].base);
+        }
         if (ev_tail) (void)hipEventRecord(ev_tail, c->stream);
+        OrbitTable ot = c->orbits;
+        if (hex_binned) ot.total = c->owned_total;      // the f_6 orbit tables are applied chunk by chunk (k_hex_apply)
         if (c->update_rule == 1) {
             if (c->n >= 4)
-                k_apply_orbits_mean<<<grid_for(c->orbits.total), WG, 0, c->stream>>>(c->w, dacc, c->D, c->Dcnt, Dcur, Ccur, Doth, Coth, c->owned_total,
-                                                                                        c->orbits);
+                k_apply_orbits_mean<<<grid_for(ot.total), WG, 0, c->stream>>>(c->w, dacc, c->D, c->Dcnt, Dcur, Ccur, Doth, Coth, c->owned_total, ot);
             else
                 k_apply_flat_mean<<<grid_for(c->slots), WG, 0, c->stream>>>(c->w, dacc, c->D, c->Dcnt, (uint32_t)c->slots);
         } else if (c->n >= 4) {
-            k_apply_orbits<<<grid_for(c->orbits.total), WG, 0, c->stream>>>(c->w, dacc, c->D, Dcur, Doth, c->owned_total, c->orbits);
+            k_apply_orbits<<<grid_for(ot.total), WG, 0, c->stream>>>(c->w, dacc, c->D, Dcur, Doth, c->owned_total, ot);
         } else if (flat_apart) {
             k_apply_flat_sum<<<grid_for(c->slots), WG, 0, c->stream>>>(c->w, dacc, c->D, (uint32_t)c->slots);
+        }
+        if (hex_binned) {
+            const uint32_t hb = c->orbits.o[6].base;
+            k_hex_apply<<<grid_for(HEX_SLOTS), WG, 0, c->stream>>>(c->w, dacc, c->D + hb, c->update_rule == 1 ? c->Dcnt + hb : nullptr, c->hex, c->orbits.o[6], c->orbits.o[7]);
         }
         if (c->n >= 4) c->dpar ^= 1u;
     } else {
@@ -2487,7 +2750,8 @@ int g2048_destroy(g2048_ctx* c) {
     void* bufs[] = {c->log.moves, c->log.start, c->log.meta, c->boards, c->scores, c->rng, c->prev[0], c->prev[1], c->oidx[0], c->oidx[1], c->label, c->flags, c->dw1, c->qstate,
                     c->qdw,    c->qcount, c->last_move, c->w,      c->w0,  c->delta,   c->stats,   c->scratch, c->slices, c->statbuf, c->D, c->Dcnt, c->D2, c->Dcnt2, c->pack, c->lane_id,
                     c->alt.boards, c->alt.scores, c->alt.rng, c->alt.label, c->alt.flags, c->alt.lane_id, c->alt.last_move,
-                    c->sort_keys, c->sort_keys_out, c->sort_iota, c->sort_perm, c->sort_temp};
+                    c->sort_keys, c->sort_keys_out, c->sort_iota, c->sort_perm, c->sort_temp,
+                    c->hex.count, c->hex.base, c->hex.cursor, c->hex.pairs, c->hex.work, c->hex.nwork};
     for (void* p : bufs)
         if (p && (p != (void*)c->w || c->owns_table)) (void)hipFree(p);
     if (c->h_stat) (void)hipHostFree(c->h_stat);
@@ -2995,6 +3259,23 @@ int g2048_td_steps_profiled(g2048_ctx* c, float alpha, uint32_t nsteps, float* m
     *ms_update = t[1] + t[2] + t[3];
     return G2048_OK;
 }
+
+#ifdef G2048_EXP_PHASES
+int g2048_debug_phases(unsigned long long* out8, unsigned long long* spans, int reset) {
+    std::vector<unsigned long long> all(8192 * 4 * 8, 0ull);
+    if (out8) {
+        if (hipMemcpyFromSymbol(all.data(), HIP_SYMBOL(g_phase_ticks), all.size() * 8) != hipSuccess) return G2048_ERR_HIP;
+        for (int k = 0; k < 8; ++k) out8[k] = 0;
+        for (size_t j = 0; j < all.size(); ++j) out8[j & 7] += all[j];
+    }
+    if (spans && hipMemcpyFromSymbol(spans, HIP_SYMBOL(g_wg_span), 2 * 8192 * 8) != hipSuccess) return G2048_ERR_HIP;
+    if (reset) {
+        std::fill(all.begin(), all.end(), 0ull);
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase_ticks), all.data(), all.size() * 8) != hipSuccess) return G2048_ERR_HIP;
+    }
+    return G2048_OK;
+}
+#endif
 
 int g2048_debug_owner_plan(g2048_ctx* c, uint64_t* out, uint32_t capacity, uint32_t* count) {
     if (!c || !out || !count) return c ? fail(c, G2048_ERR_ARG, "null buffer") : G2048_ERR_ARG;
