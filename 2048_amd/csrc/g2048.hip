@@ -1688,6 +1688,14 @@ __global__ __launch_bounds__(WG) void k_hex_apply(float* w, float* dacc, float* 
 // copy pass).  The host never sees the order: lane_id travels with the lane and every lane-addressed entry point of the
 // ABI first restores the identity order (k_restore_order).
 constexpr uint32_t SORT_TILE = 5;
+#ifndef G2048_SORT_CELL_BITS
+#define G2048_SORT_CELL_BITS 3
+#endif
+#ifndef G2048_SORT_STEP
+#define G2048_SORT_STEP 1
+#endif
+constexpr int SORT_CELL_BITS = G2048_SORT_CELL_BITS;       // key bits per cell
+constexpr uint32_t SORT_STEP = G2048_SORT_STEP;            // tiles per key value above SORT_TILE
 
 __global__ __launch_bounds__(WG) void k_iota(uint32_t* v, uint32_t n) {
     uint32_t i = blockIdx.x * WG + threadIdx.x;
@@ -1698,18 +1706,19 @@ __global__ __launch_bounds__(WG) void k_sort_keys(const uint4* boards, uint32_t 
     uint32_t i = blockIdx.x * WG + threadIdx.x;
     if (i >= B) return;
     const Board b = ld_board(boards, i);
-    uint64_t key = 0;           // 3 bits per cell, row-major: 0 for a tile <= SORT_TILE, else tile - SORT_TILE (7 = that and above)
+    uint64_t key = 0;           // SORT_CELL_BITS per cell, row-major: 0 for a tile <= SORT_TILE, else how far above (saturating)
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int col = 0; col < 4; ++col) {
             const uint32_t v = (b.r[r] >> (8 * col)) & 0xFFu;
-            const uint32_t code = v > SORT_TILE ? (v - SORT_TILE > 7u ? 7u : v - SORT_TILE) : 0u;
-            key = (key << 3) | code;
+            constexpr uint32_t TOP = (1u << SORT_CELL_BITS) - 1u;
+            const uint32_t over = v > SORT_TILE ? (v - SORT_TILE + SORT_STEP - 1u) / SORT_STEP : 0u;
+            key = (key << SORT_CELL_BITS) | (over > TOP ? TOP : over);
         }
     keys[i] = key;
 }
-constexpr int SORT_KEY_BITS = 48;
+constexpr int SORT_KEY_BITS = 16 * SORT_CELL_BITS;
 
 struct CarrySet {       // the `state` of QAgent.episode and its orbit indices (prev[cur], oidx[cur])
     uint4* prev;
