@@ -635,8 +635,8 @@ struct TdRecs {
     float* qdw;             // [B]
     uint32_t* qcount;       // length of this step's queue
     uint32_t* qcount_next;  // next step's counter, zeroed by k_td_play
-    uint32_t* blocks;       // k_td_play's work counter: the next lane block to hand out
-    uint32_t* blocks_next;  // next step's, zeroed by k_td_play
+    uint32_t* blocks;       // [8] k_td_play's work counters (one per XCD segment): the next 64-lane block to hand out
+    uint32_t* blocks_next;  // [8] next step's, zeroed by k_td_play
     uint32_t unit;          // 1: every record counts as dw = 1 (the counting pass of the per-slot mean rule)
     uint32_t* dwmax;        // float bits of the largest |dw| among this step's records (scale of the fixed-point sums)
     uint32_t* dwmax_next;   // next step's, zeroed by k_td_play
@@ -766,55 +766,65 @@ __device__ unsigned long long g_wg_span[2 * 8192];
 // step's afterstate, so the main record needs no copy.
 // `perm` (null on ordinary steps, when in == out): position i of the new lane order takes the lane now at position perm[i];
 // the step's records stay in the OLD order (dw1 is written at perm[i], where the update kernels find the lane's `state`).
+#ifndef G2048_PLAY_MIN_WAVES      // (experiment: minimum waves per SIMD the register allocation of k_td_play must allow; 0 = compiler's choice)
+#define G2048_PLAY_MIN_WAVES 0
+#endif
 template <int N, int TPB, bool HOT>
-__global__ __launch_bounds__(TPB) void k_td_play(LaneSet in, LaneSet out, const uint32_t* __restrict__ perm, uint4* prev_nxt,
+__global__ __launch_bounds__(TPB, G2048_PLAY_MIN_WAVES) void k_td_play(LaneSet in, LaneSet out, const uint32_t* __restrict__ perm, uint4* prev_nxt,
                                                  uint32_t B, const float* __restrict__ w, float alpha, TdRecs recs, int auto_reset,
                                                  Stats* stats, GameLog lg, uint32_t static_rounds) {
     constexpr float F = (float)Shape<N>::F;
-    constexpr uint32_t WG = TPB;        // (shadows the file-wide 256: lane blocks are as wide as the workgroup)
     __shared__ WgStats ws;
     __shared__ float hot[HOT ? HOT_SLOTS : 1];
     wg_stats_init(&ws);
     if constexpr (HOT) load_hot_set<TPB>(hot, w);
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        *recs.qcount_next = 0;
-        *recs.dwmax_next = 0;
-        *recs.blocks_next = 0;
+    if (blockIdx.x == 0 && threadIdx.x < 8) {
+        recs.blocks_next[threadIdx.x] = 0;
+        if (threadIdx.x == 0) {
+            *recs.qcount_next = 0;
+            *recs.dwmax_next = 0;
+        }
     }
-    // Persistent workgroups: the grid is what the chip holds at once (play_grid) and a workgroup takes lane blocks from a
-    // counter until none is left — the hardware's balance (a free slot takes the next block) is kept, no workgroup
-    // launches, one statistics flush per workgroup.  The first `static_rounds` blocks of a workgroup are g, g + G, ... (no
-    // counter, no barrier: its waves run on independently).  The counter is read ONE BLOCK AHEAD: the returning atomic is
-    // issued before the block's loads and stores, so that waiting for it at the next hand-out does not wait for those
-    // stores (vmcnt retires in order).  Measured at 2^20 lanes, n = 5: all rounds from the counter 0.213-0.230 ms, all but
-    // one static 0.194-0.218 ms, all static 0.230-0.242 ms (gpurun_out r02p).
+    // Persistent WAVES: the grid is what the chip holds at once (play_grid) and every wave takes 64-lane blocks until none
+    // is left — no barrier anywhere in the loop, the waves of a workgroup run on independently.  The first `static_rounds`
+    // blocks of wave v are v, v + V, v + 2V ... (V waves in the grid); the blocks behind them are cut into 8 segments, one
+    // per XCD (blockIdx % 8), each handed out through its own counter, which keeps the hardware's balance at the end of the
+    // launch (a wave that is ahead takes more) without thousands of returning atomics on one address.  The counter is read
+    // ONE BLOCK AHEAD: the atomic is issued before the block's loads and stores, so that waiting for it does not wait for
+    // those stores (vmcnt retires in order).
 #ifdef G2048_EXP_PHASES
     unsigned long long phase_t_ = wall_clock64();
     unsigned long long phase_acc_[8] = {};
     if (threadIdx.x == 0 && blockIdx.x < 8192) g_wg_span[2 * blockIdx.x] = phase_t_;
 #endif
-    __shared__ uint32_t next_block[2];
-    const uint32_t nblocks = (B + WG - 1) / WG;
-    uint32_t ahead = 0;
-    if (threadIdx.x == 0 && static_rounds == 0) ahead = atomicAdd(recs.blocks, 1u);
+    constexpr uint32_t WAVES = TPB / 64;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t nwaves = gridDim.x * WAVES, wave_id = blockIdx.x * WAVES + (threadIdx.x >> 6);
+    const uint32_t nblocks = (B + 63u) / 64u;
+    const uint32_t dyn0 = static_rounds * nwaves < nblocks ? static_rounds * nwaves : nblocks;     // first block of the dynamic region
+    const uint32_t nseg = gridDim.x < 8u ? gridDim.x : 8u;         // (a small grid does not reach all 8 XCDs)
+    const uint32_t seg = blockIdx.x % nseg, seg_len = (nblocks - dyn0 + nseg - 1u) / nseg;
+    const uint32_t seg_lo = dyn0 + seg * seg_len, seg_hi = seg_lo + seg_len < nblocks ? seg_lo + seg_len : nblocks;
+    uint32_t* const counter = recs.blocks + seg;
+    uint32_t ahead = 0, my_moves = 0, my_dirs = 0;
+    float dw_big = 0.0f;            // largest |dw| this lane emits in the whole launch
+    if (lane == 0 && static_rounds == 0) ahead = seg_lo + atomicAdd(counter, 1u);
     for (uint32_t it = 0;; ++it) {
     uint32_t blk;
     if (it < static_rounds) {
-        blk = it * gridDim.x + blockIdx.x;
-        if (threadIdx.x == 0 && it + 1 == static_rounds) ahead = static_rounds * gridDim.x + atomicAdd(recs.blocks, 1u);
+        blk = it * nwaves + wave_id;
+        if (lane == 0 && it + 1 == static_rounds) ahead = seg_lo + atomicAdd(counter, 1u);
     } else {
-        if (threadIdx.x == 0) next_block[it & 1u] = ahead;
-        __syncthreads();        // (the other slot is rewritten only after every thread has passed the next barrier)
-        blk = next_block[it & 1u];
-        if (threadIdx.x == 0 && blk < nblocks) ahead = static_rounds * gridDim.x + atomicAdd(recs.blocks, 1u);
+        blk = (uint32_t)__builtin_amdgcn_readfirstlane((int)ahead);
+        if (blk >= seg_hi) break;
+        if (lane == 0) ahead = seg_lo + atomicAdd(counter, 1u);
     }
     if (blk >= nblocks) break;
     PHASE_STAMP(0);             // block hand-out
-    const uint32_t base = blk * WG;
-    const uint32_t i = base + threadIdx.x;
+    const uint32_t i = blk * 64u + lane;
+
     bool moved = false;
     uint32_t ndirs = 0;             // directions that were open to this lane's move
-    float dw_big = 0.0f;            // largest |dw| this lane emits
     if (i < B) {
         const uint32_t src = perm ? perm[i] : i;
         // the whole lane state is requested at once: loading the flags first and the rest behind the DONE test would put two
@@ -880,7 +890,7 @@ __global__ __launch_bounds__(TPB) void k_td_play(LaneSet in, LaneSet out, const 
                     const float dw2 = -c.value * alpha / F;
                     if (isfinite(dw2)) {
                         push_terminal(recs, after, dw2);
-                        dw_big = fabsf(dw2);
+                        dw_big = fmaxf(dw_big, fabsf(dw2));
                     } else {
                         atomicAdd(&ws.nonfinite, 1u);
                     }
@@ -893,7 +903,7 @@ __global__ __launch_bounds__(TPB) void k_td_play(LaneSet in, LaneSet out, const 
                     const float dw2 = -old_label * alpha / F;
                     if (isfinite(dw2)) {
                         push_terminal(recs, ld_packed(recs.state1, src), dw2);
-                        dw_big = fabsf(dw2);
+                        dw_big = fmaxf(dw_big, fabsf(dw2));
                     } else {
                         atomicAdd(&ws.nonfinite, 1u);
                     }
@@ -914,6 +924,7 @@ __global__ __launch_bounds__(TPB) void k_td_play(LaneSet in, LaneSet out, const 
                 }
             }
             if (lid < lg.lanes) log_step(lg, lid, lm, moved, over, final_score, over && auto_reset, b);
+            PHASE_STAMP(6);     // (finished games: statistics, new game)
             st_board(out.boards, i, b);
             st_rng(out.rng, i, g);
             out.scores[i] = score;
@@ -929,11 +940,15 @@ __global__ __launch_bounds__(TPB) void k_td_play(LaneSet in, LaneSet out, const 
         recs.dw1[src] = dw1;
         out.last_move[i] = (uint16_t)lm;
         dw_big = fmaxf(dw_big, fabsf(dw1));
+        PHASE_STAMP(7);         // (stores issued)
     }
+    my_moves += moved ? 1u : 0u;
+    my_dirs += ndirs;
+    PHASE_STAMP(4);
+    }
+    // the wave reductions happen once per launch, not once per block (they cost 2.4 us of a block's 22 there)
     if (dw_big > 0.0f) atomicMax(&ws.dw_max_bits, __float_as_uint(dw_big));
-    count_moves(&ws, moved ? 1u : 0u, ndirs);
-    PHASE_STAMP(4);             // reset, stores (issued), statistics
-    }
+    count_moves(&ws, my_moves, my_dirs);
     wg_stats_flush(&ws, stats);
     if (threadIdx.x == 0 && ws.dw_max_bits) atomicMax(recs.dwmax, ws.dw_max_bits);
 #ifdef G2048_EXP_PHASES
@@ -1831,7 +1846,7 @@ struct g2048_ctx {
     float* dw1 = nullptr;               // main record of every lane (0 = none)
     uint4* qstate = nullptr;            // terminal-record queue
     float* qdw = nullptr;
-    uint32_t* qcount = nullptr;         // [6]: this / next step's queue length, largest |dw| bits, k_td_play block counter
+    uint32_t* qcount = nullptr;         // [32]: this / next step's queue length [0,1], largest |dw| bits [2,3], k_td_play's 8 block counters [8..15], [16..23]
     uint16_t* last_move = nullptr;      // what every lane did in the latest TD step (g2048_get_last_move)
     // lane order (LaneSort): boards / scores / rng / label / flags / last_move / lane_id above are the CURRENT set; `alt` is
     // the other one (allocated with the first re-ordering)
@@ -2551,7 +2566,7 @@ unsigned play_grid(g2048_ctx* c) {
 
 // how many lane blocks every workgroup of k_td_play takes without asking the counter: all full rounds but `play_dynamic`
 uint32_t play_static_rounds(const g2048_ctx* c, unsigned grid, unsigned tpb) {
-    const uint32_t nblocks = (uint32_t)(((uint64_t)c->B + tpb - 1) / tpb), full = nblocks / grid;
+    const uint32_t nblocks = (uint32_t)(((uint64_t)c->B + 63) / 64), nwaves = grid * (tpb / 64), full = nblocks / nwaves;
     return full > c->knob.play_dynamic ? full - c->knob.play_dynamic : 0u;
 }
 
@@ -2572,8 +2587,8 @@ int launch_td_step(g2048_ctx* c, float alpha, hipEvent_t ev = nullptr, hipEvent_
     recs.qcount_next = c->qcount + (c->step_parity ^ 1u);
     recs.dwmax = c->qcount + 2 + c->step_parity;
     recs.dwmax_next = c->qcount + 2 + (c->step_parity ^ 1u);
-    recs.blocks = c->qcount + 4 + c->step_parity;
-    recs.blocks_next = c->qcount + 4 + (c->step_parity ^ 1u);
+    recs.blocks = c->qcount + 8 + 8 * c->step_parity;
+    recs.blocks_next = c->qcount + 8 + 8 * (c->step_parity ^ 1u);
     recs.unit = 0;
     recs.oidx = c->oidx[c->cur];
     recs.oidx_nxt = c->oidx[c->cur ^ 1];
@@ -2820,7 +2835,7 @@ static int create_impl(int device, uint32_t batch, int n_tuple, uint64_t seed, u
     if ((rc = dalloc(c, &c->boards, B)) || (rc = dalloc(c, &c->scores, B)) || (rc = dalloc(c, &c->rng, B)) ||
         (rc = dalloc(c, &c->prev[0], B)) || (rc = dalloc(c, &c->prev[1], B)) || (rc = dalloc(c, &c->label, B)) ||
         (rc = dalloc(c, &c->flags, B)) || (rc = dalloc(c, &c->dw1, B)) || (rc = dalloc(c, &c->qstate, B)) || (rc = dalloc(c, &c->qdw, B)) ||
-        (rc = dalloc(c, &c->qcount, 8)) || (rc = dalloc(c, &c->last_move, B)) || (rc = dalloc(c, &c->lane_id, B)) ||
+        (rc = dalloc(c, &c->qcount, 32)) || (rc = dalloc(c, &c->last_move, B)) || (rc = dalloc(c, &c->lane_id, B)) ||
         (rc = dalloc(c, &c->stats, 1)))
         return bail(rc);
     if (n_tuple >= 4 && ((rc = dalloc(c, &c->oidx[0], OIDX_BYTES_PER_LANE * B)) || (rc = dalloc(c, &c->oidx[1], OIDX_BYTES_PER_LANE * B)))) return bail(rc);
@@ -2840,7 +2855,7 @@ static int create_impl(int device, uint32_t batch, int n_tuple, uint64_t seed, u
     if (hipMemsetAsync(c->stats, 0, sizeof(Stats), c->stream) != hipSuccess ||
         hipMemsetAsync(c->prev[0], 0, B * sizeof(uint4), c->stream) != hipSuccess ||
         hipMemsetAsync(c->prev[1], 0, B * sizeof(uint4), c->stream) != hipSuccess ||
-        hipMemsetAsync(c->qcount, 0, 32, c->stream) != hipSuccess || hipMemsetAsync(c->last_move, 0, B * 2, c->stream) != hipSuccess || hipMemsetAsync(c->dw1, 0, B * 4, c->stream) != hipSuccess ||
+        hipMemsetAsync(c->qcount, 0, 128, c->stream) != hipSuccess || hipMemsetAsync(c->last_move, 0, B * 2, c->stream) != hipSuccess || hipMemsetAsync(c->dw1, 0, B * 4, c->stream) != hipSuccess ||
         (slots && !parent && hipMemsetAsync(c->w, 0, slots * sizeof(float), c->stream) != hipSuccess))
         return bail(G2048_ERR_HIP);
     k_iota<<<grid_for(B), WG, 0, c->stream>>>(c->lane_id, batch);

@@ -21,11 +21,11 @@ k = eng.td_steps_kernel_ms(alpha, steps)
 eng.sync()
 lib.g2048_debug_phases(out, spans.ctypes.data_as(ctypes.c_void_p), 0)
 waves = B / 64 * steps
-names = ['block hand-out (barrier, counter)', 'state loads + moves', 'features, gathers, sums, select', 'pick, spawn, terminal, orbit idx', 'reset, stores, statistics',
-         'leaving the loop + flush']
+names = ['block hand-out (barrier, counter)', 'state loads + moves', 'features, gathers, sums, select', 'pick, spawn, terminal, orbit idx', 'dw max + move counts (wave reductions)',
+         'leaving the loop + flush', 'finished games: statistics, new game', 'stores (issue)']
 print(f'k_td_play {k[0] * 1e3:.1f} us; mean microseconds per wave and 64-lane block, by phase:')
 tot = 0
-for j in range(6):
+for j in range(8):
     us = out[j] / waves / 100.0
     tot += us
     print(f'  {names[j]:36s} {us:8.2f} us')
