@@ -1043,6 +1043,9 @@ G2048_HD uint32_t permute_digits(uint32_t k, uint32_t perm, uint32_t digits, uin
     return out;
 }
 
+#ifndef G2048_OWN_U
+#define G2048_OWN_U 4       // records per thread in flight in the owner kernel's scan (n >= 4)
+#endif
 constexpr int OWN_WG = 1024;
 constexpr uint32_t OWN_SLOTS = 32768;      // 128 KiB of the CU's 160 KiB LDS
 template <int FC> struct OwnUnroll { static constexpr int U = FC == 1 ? 4 : 1; };   // records in flight per thread (loads issued together)
@@ -1157,7 +1160,7 @@ __device__ __forceinline__ void own_run(float* acc, const Slice& s, const TdRecs
     uint32_t nhit = 0, nhit_wave = 0;
     if constexpr (N >= 4) {
         // main records from their precomputed orbit indices: 8 B (cross: 16 B, centre square: 2 B) + dw per record
-        constexpr int NI = V == 4 ? 1 : 4, U = 4;
+        constexpr int NI = V == 4 ? 1 : 4, U = G2048_OWN_U;
         const OrbitIdx oi = orbit_idx(recs.oidx, B);
         const uint32_t lo_rel = s.tlo - s.orb_tlo;
         // a part takes every nparts-th block of records, not one contiguous range: the lanes may be ordered by board
@@ -1315,6 +1318,20 @@ __global__ __launch_bounds__(OWN_WG) void k_td_update_owner(float* dst, float* c
     if (threadIdx.x == 0) wg_clock[2 * blockIdx.x + 1] = wall_clock64();
 }
 
+// The planner's statistics (hit counters + workgroup clocks of the owner kernel that just ran, 17 KB) go to their pinned
+// host mirror from inside the apply kernel — the first blocks store them over PCIe — instead of through a copy command:
+// a blit kernel on a side stream took 11-17 us beside every k_td_play (rocprofv3, round 2).
+struct StatMirror {
+    const uint32_t* src;    // device: statbuf
+    uint32_t* dst;          // pinned host memory (device-visible); null: no mirror this step
+    uint32_t words;
+};
+__device__ __forceinline__ void mirror_stats(const StatMirror& m) {
+    if (!m.dst) return;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m.words) m.dst[i] = __hip_atomic_load(&m.src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (written by the previous kernel: bypass a stale L1 line)
+}
+
 // table_i[perm_i(k)] += v for every member i of the orbit; `dacc` (may be null) mirrors the add (g2048_delta_begin)
 __device__ __forceinline__ void add_to_members(float* w, float* dacc, const OrbitInfo& oi, uint32_t k, float v) {
     for (uint32_t m = 0; m < oi.nmem; ++m) {
@@ -1329,7 +1346,9 @@ __device__ __forceinline__ void add_to_members(float* w, float* dacc, const Orbi
 // The LDS-owned orbit tables [0, owned) are double-buffered (cur: this step's sums, oth: the next step's, cleared here;
 // a clear in place would race with the threads that read E[sigma(k)]; a memset between the steps costs a launch and, in
 // ROCclr, ~20 us of idle queue); the f_6 orbit tables behind them live in D and are cleared in place.
-__global__ __launch_bounds__(WG) void k_apply_orbits(float* w, float* dacc, float* D, const float* cur, float* oth, uint32_t owned, OrbitTable t) {
+__global__ __launch_bounds__(WG) void k_apply_orbits(float* w, float* dacc, float* D, const float* cur, float* oth, uint32_t owned, OrbitTable t,
+                                                      StatMirror sm) {
+    mirror_stats(sm);
     const uint32_t K = blockIdx.x * WG + threadIdx.x;
     if (K >= t.total) return;
     if (K < owned) oth[K] = 0.0f;
@@ -1365,7 +1384,8 @@ __global__ __launch_bounds__(WG) void k_apply_orbits(float* w, float* dacc, floa
 // Per-slot mean rule (g2048_set_update_rule): S = sum of the dw that target a slot, C = how many did; the slot moves
 // by S / C.  S and C come from two runs of the same accumulation (the second with dw = 1).
 __global__ __launch_bounds__(WG) void k_apply_orbits_mean(float* w, float* dacc, float* S, float* C, const float* scur, const float* ccur, float* soth,
-                                                          float* coth, uint32_t owned, OrbitTable t) {
+                                                          float* coth, uint32_t owned, OrbitTable t, StatMirror sm) {
+    mirror_stats(sm);
     const uint32_t K = blockIdx.x * WG + threadIdx.x;
     if (K >= t.total) return;
     if (K < owned) {
@@ -1838,6 +1858,7 @@ struct g2048_ctx {
     uint64_t* wg_clock = nullptr;               // [MAX_SLICES][2] start / end clock of every owner workgroup (last launch)
     uint8_t* statbuf = nullptr;                 // one allocation: hit counters | workgroup clocks (one copy reads both back)
     uint8_t* h_stat = nullptr;                  // pinned host mirrors: statbuf, and the staging of the slices
+    void* h_stat_dev = nullptr;                 // h_stat as the device sees it (the apply kernels store the statistics there)
     Slice* h_slices = nullptr;
     std::vector<uint32_t> hits_seen;            // the counters are cumulative (mod 2^32); what the last readback saw
     std::vector<Slice> plan;                    // host copy of the slices in use
@@ -1882,8 +1903,6 @@ struct g2048_ctx {
     uint32_t replan_interval = 1;   // steps until the next unconditional replan: 1, 2, 4, ... replan_every after a (re)start
     double makespan_ref = 0;        // owner kernel makespan (100 MHz ticks) of the first launch under the current plan
     bool plan_measured = false;     // the load is a measurement (not the creation-time prior)
-    hipStream_t side = nullptr;     // carries the statistics read-back so that it overlaps k_td_play
-    hipEvent_t ev_upd = nullptr;    // end of a step's update on `stream`
     hipEvent_t ev_table = nullptr;  // last table-touching launch on `stream` (contexts that share a table wait on it)
     g2048_ctx* parent = nullptr;    // owner of the shared table (g2048_create_shared); null: this context owns `w`
     uint32_t shared_users = 0;      // (owner only) contexts created on this table with g2048_create_shared and still alive
@@ -2320,7 +2339,8 @@ int build_slices(g2048_ctx* c) {
         HIP_TRY(c, hipMemset(c->statbuf, 0, STAT_BYTES));
         c->hits = reinterpret_cast<uint32_t*>(c->statbuf);
         c->wg_clock = reinterpret_cast<uint64_t*>(c->statbuf + HITS_CAP * 4);
-        HIP_TRY(c, hipHostMalloc((void**)&c->h_stat, STAT_BYTES, hipHostMallocDefault));
+        HIP_TRY(c, hipHostMalloc((void**)&c->h_stat, STAT_BYTES, hipHostMallocMapped));
+        HIP_TRY(c, hipHostGetDevicePointer(&c->h_stat_dev, c->h_stat, 0));
         HIP_TRY(c, hipHostMalloc((void**)&c->h_slices, MAX_SLICES * sizeof(Slice), hipHostMallocDefault));
     }
     const std::vector<ChunkInfo> chunks = table_chunks(c);
@@ -2472,14 +2492,11 @@ int build_slices(g2048_ctx* c) {
 }
 
 // Planner feedback, first half (BEFORE the step's k_td_play is launched): the hit counters and the workgroup clocks of
-// the update launches so far are copied into pinned memory on the SIDE stream, behind the previous step's update, so
-// that the copy runs beside k_td_play instead of in front of it.
+// the update launches so far were stored into pinned host memory by the previous step's apply kernel (mirror_stats); an
+// event marks that kernel's end.
 int stats_readback(g2048_ctx* c) {
     if (c->n < 4 || c->n_chunks == 0 || c->steps_since_read == 0) return G2048_OK;
-    HIP_TRY(c, hipEventRecord(c->ev_upd, c->stream));
-    HIP_TRY(c, hipStreamWaitEvent(c->side, c->ev_upd, 0));
-    HIP_TRY(c, hipMemcpyAsync(c->h_stat, c->statbuf, STAT_BYTES, hipMemcpyDeviceToHost, c->side));
-    HIP_TRY(c, hipEventRecord(c->ev_plan, c->side));
+    HIP_TRY(c, hipEventRecord(c->ev_plan, c->stream));      // behind the previous step's apply kernel, which stored the statistics
     c->plan_pending = true;
     return G2048_OK;
 }
@@ -2671,15 +2688,17 @@ int launch_td_step(g2048_ctx* c, float alpha, hipEvent_t ev = nullptr, hipEvent_
             k_td_update_tail<6><<<tail_grid, OWN_WG, 0, c->stream>>>(c->D, recs, B, c->orbits.o[6].base, c->orbits.o[7].base);
         }
         if (ev_tail) (void)hipEventRecord(ev_tail, c->stream);
+        const StatMirror sm{reinterpret_cast<const uint32_t*>(c->statbuf), c->n >= 4 ? reinterpret_cast<uint32_t*>(c->h_stat_dev) : nullptr,
+                            (uint32_t)(STAT_BYTES / 4)};
         OrbitTable ot = c->orbits;
         if (hex_binned) ot.total = c->owned_total;      // the f_6 orbit tables are applied chunk by chunk (k_hex_apply)
         if (c->update_rule == 1) {
             if (c->n >= 4)
-                k_apply_orbits_mean<<<grid_for(ot.total), WG, 0, c->stream>>>(c->w, dacc, c->D, c->Dcnt, Dcur, Ccur, Doth, Coth, c->owned_total, ot);
+                k_apply_orbits_mean<<<grid_for(ot.total), WG, 0, c->stream>>>(c->w, dacc, c->D, c->Dcnt, Dcur, Ccur, Doth, Coth, c->owned_total, ot, sm);
             else
                 k_apply_flat_mean<<<grid_for(c->slots), WG, 0, c->stream>>>(c->w, dacc, c->D, c->Dcnt, (uint32_t)c->slots);
         } else if (c->n >= 4) {
-            k_apply_orbits<<<grid_for(ot.total), WG, 0, c->stream>>>(c->w, dacc, c->D, Dcur, Doth, c->owned_total, ot);
+            k_apply_orbits<<<grid_for(ot.total), WG, 0, c->stream>>>(c->w, dacc, c->D, Dcur, Doth, c->owned_total, ot, sm);
         } else if (flat_apart) {
             k_apply_flat_sum<<<grid_for(c->slots), WG, 0, c->stream>>>(c->w, dacc, c->D, (uint32_t)c->slots);
         }
@@ -2782,12 +2801,7 @@ int g2048_destroy(g2048_ctx* c) {
     if (c->h_slices) (void)hipHostFree(c->h_slices);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev_plan) (void)hipEventDestroy(c->ev_plan);
-    if (c->ev_upd) (void)hipEventDestroy(c->ev_upd);
     if (c->ev_table) (void)hipEventDestroy(c->ev_table);
-    if (c->side) {
-        (void)hipStreamSynchronize(c->side);
-        (void)hipStreamDestroy(c->side);
-    }
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -2822,12 +2836,9 @@ static int create_impl(int device, uint32_t batch, int n_tuple, uint64_t seed, u
         return code;
     };
     if (hipSetDevice(device) != hipSuccess) return bail(G2048_ERR_HIP);
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess)
-        return bail(G2048_ERR_HIP);
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail(G2048_ERR_HIP);
     if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_plan, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_upd, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_table, hipEventDisableTiming) != hipSuccess)
         return bail(G2048_ERR_HIP);
     read_knobs(c);
