@@ -521,8 +521,12 @@ class QAgent:
                 benchmark_time = check_thread(parent, benchmark_time)
                 if not benchmark_time:
                     return
-            if self.step > self.next_decay and self.alpha > self.low_alpha_limit:
+            # r_learning.py:293-294 looks at the episode counter before every game; here it jumps by thousands per chunk,
+            # so every decay_step boundary that was passed decays once, as the per-episode check would have
+            while self.step > self.next_decay and self.alpha > self.low_alpha_limit:
+                due = self.next_decay
                 self.decay_alpha()
+                self.next_decay = due + self.decay_step
             eng.td_steps(self.device_alpha(), chunk)
             if sync is not None:
                 sync.all_reduce()
