@@ -78,6 +78,7 @@ SIGNATURES = {
     'g2048_log_enable': (c_int, [_P, c_uint32, c_uint32]),
     'g2048_log_meta': (c_int, [_P, _P]),
     'g2048_log_game': (c_int, [_P, c_uint32, c_uint32, _P, _P]),
+    'g2048_log_final': (c_int, [_P, c_uint32, c_uint32, _P]),
     'g2048_stats_get': (c_int, [_P, POINTER(Stats)]),
     'g2048_stats_reset': (c_int, [_P]),
     'g2048_weights_device_ptr': (c_int, [_P, POINTER(_P), POINTER(c_int64)]),

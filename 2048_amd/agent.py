@@ -446,20 +446,27 @@ class QAgent:
 
     WATCHED_LANES, LOG_CAPACITY = 1024, 16384
 
-    def _game_from_log(self, eng, lane, slot, length, score):
-        """Rebuild a reference `Game` (moves, tiles, starting_position, final row) from a device game record."""
+    def _game_from_log(self, eng, lane, slot, length, score, verify=False):
+        """A reference `Game` (moves, tiles, starting_position, final row, score, odometer) from a device game record.
+        verify: also replay the record move by move (Game.make_move) and check that it leads to the recorded end."""
         words, start = eng.log_game(lane, slot)
-        game = Game(row=start.astype(np.int32))
+        game = Game(score=score, row=eng.log_final(lane, slot).astype(np.int32))
         game.starting_position = start.astype(np.int32)
+        game.odometer = length
         for lm in words[:length]:
             lm = int(lm)
-            game.make_move(lm & 3)
+            game.moves.append(lm & 3)
             if lm & (1 << 10):
-                cell = ((lm >> 4) & 15) >> 2, ((lm >> 4) & 15) & 3
-                game.row[cell] = (lm >> 8) & 3
-                game.tiles.append(((lm >> 8) & 3, cell))
+                game.tiles.append(((lm >> 8) & 3, (((lm >> 4) & 15) >> 2, ((lm >> 4) & 15) & 3)))
         game.moves.append(-1)
-        assert game.score == score, 'device game record does not replay to its score'
+        if verify:
+            check = Game(row=start.astype(np.int32))
+            for lm in words[:length]:
+                lm = int(lm)
+                check.make_move(lm & 3)
+                if lm & (1 << 10):
+                    check.row[((lm >> 4) & 15) >> 2, ((lm >> 4) & 15) & 3] = (lm >> 8) & 3
+            assert check.score == score and np.array_equal(check.row, game.row), 'device game record does not replay to its end'
         return game
 
     def _collect_best_games(self, eng, seen, saving):

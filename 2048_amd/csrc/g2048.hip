@@ -707,6 +707,7 @@ struct GameLog {
     uint32_t lanes, capacity;       // lanes == 0: off
     uint16_t* moves;                // [lanes][2][capacity] g2048_get_last_move words, one per move
     uint4* start;                   // [lanes][2] starting boards
+    uint4* final;                   // [lanes][2] boards the games ended on
     uint32_t* meta;                 // [lanes][8]: slot in use, moves so far, games finished, {length, score} of slot 0, of slot 1, flags
 };
 constexpr uint32_t LOG_PARTIAL0 = 1u, LOG_TRUNC0 = 4u;     // flags: bit s = slot s did not start at move 0; bit 2 + s = slot s overflowed
@@ -722,7 +723,7 @@ __global__ __launch_bounds__(WG) void k_log_init(GameLog lg, const uint4* boards
 }
 
 __device__ __forceinline__ void log_step(const GameLog& lg, uint32_t i, uint32_t lm, bool moved, bool over, int32_t final_score,
-                                         bool restarted, const Board& fresh) {
+                                         bool restarted, const Board& fresh, const Board& last) {
     uint32_t* m = lg.meta + 8 * i;
     uint32_t slot = m[0], cnt = m[1];
     if (moved) {
@@ -736,6 +737,7 @@ __device__ __forceinline__ void log_step(const GameLog& lg, uint32_t i, uint32_t
         m[3 + 2 * slot] = cnt;
         m[4 + 2 * slot] = (uint32_t)final_score;
         m[2] += 1;
+        st_board(lg.final, (size_t)i * 2 + slot, last);
         if (restarted) {
             slot ^= 1u;
             cnt = 0;
@@ -911,6 +913,7 @@ __global__ __launch_bounds__(TPB, G2048_PLAY_MIN_WAVES) void k_td_play(LaneSet i
             }
             PHASE_STAMP(3);     // pick, spawn, terminal test, orbit indices
             const int32_t final_score = score;
+            const Board final_board = b;
             if (over) {
                 lm |= 1u << 11;
                 count_finished(&ws, b, score, overflow);
@@ -923,7 +926,7 @@ __global__ __launch_bounds__(TPB, G2048_PLAY_MIN_WAVES) void k_td_play(LaneSet i
                     fl |= DONE;
                 }
             }
-            if (lid < lg.lanes) log_step(lg, lid, lm, moved, over, final_score, over && auto_reset, b);
+            if (lid < lg.lanes) log_step(lg, lid, lm, moved, over, final_score, over && auto_reset, b, final_board);
             PHASE_STAMP(6);     // (finished games: statistics, new game)
             st_board(out.boards, i, b);
             st_rng(out.rng, i, g);
@@ -1880,7 +1883,7 @@ struct g2048_ctx {
     uint32_t *sort_iota = nullptr, *sort_perm = nullptr;
     void* sort_temp = nullptr;
     size_t sort_temp_bytes = 0;
-    GameLog log = {0, 0, nullptr, nullptr, nullptr};
+    GameLog log = {0, 0, nullptr, nullptr, nullptr, nullptr};
     uint32_t step_parity = 0;
     float *w = nullptr, *w0 = nullptr, *delta = nullptr;
     // multi-GPU epoch state (g2048_delta_begin): W0 = table at the start of the epoch; `delta` accumulates every add this
@@ -2790,7 +2793,7 @@ int g2048_destroy(g2048_ctx* c) {
         if (c->parent->shared_users) --c->parent->shared_users;
         if (c->parent->last_user == c) c->parent->last_user = nullptr;
     }
-    void* bufs[] = {c->log.moves, c->log.start, c->log.meta, c->boards, c->scores, c->rng, c->prev[0], c->prev[1], c->oidx[0], c->oidx[1], c->label, c->flags, c->dw1, c->qstate,
+    void* bufs[] = {c->log.moves, c->log.start, c->log.final, c->log.meta, c->boards, c->scores, c->rng, c->prev[0], c->prev[1], c->oidx[0], c->oidx[1], c->label, c->flags, c->dw1, c->qstate,
                     c->qdw,    c->qcount, c->last_move, c->w,      c->w0,  c->delta,   c->stats,   c->scratch, c->slices, c->statbuf, c->D, c->Dcnt, c->D2, c->Dcnt2, c->pack, c->lane_id,
                     c->alt.boards, c->alt.scores, c->alt.rng, c->alt.label, c->alt.flags, c->alt.lane_id, c->alt.last_move,
                     c->sort_keys, c->sort_keys_out, c->sort_iota, c->sort_perm, c->sort_temp,
@@ -3348,12 +3351,13 @@ int g2048_log_enable(g2048_ctx* c, uint32_t lanes, uint32_t capacity) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (c->log.moves) (void)hipFree(c->log.moves);
     if (c->log.start) (void)hipFree(c->log.start);
+    if (c->log.final) (void)hipFree(c->log.final);
     if (c->log.meta) (void)hipFree(c->log.meta);
-    c->log = GameLog{0, 0, nullptr, nullptr, nullptr};
+    c->log = GameLog{0, 0, nullptr, nullptr, nullptr, nullptr};
     if (lanes == 0) return G2048_OK;
     int rc;
     if ((rc = dalloc(c, &c->log.moves, (size_t)lanes * 2 * capacity)) || (rc = dalloc(c, &c->log.start, (size_t)lanes * 2)) ||
-        (rc = dalloc(c, &c->log.meta, (size_t)lanes * 8)))
+        (rc = dalloc(c, &c->log.final, (size_t)lanes * 2)) || (rc = dalloc(c, &c->log.meta, (size_t)lanes * 8)))
         return rc;
     c->log.lanes = lanes;
     c->log.capacity = capacity;
@@ -3376,6 +3380,14 @@ int g2048_log_game(g2048_ctx* c, uint32_t lane, uint32_t slot, uint16_t* moves, 
     int rc;
     if ((rc = d2h(c, moves, c->log.moves + ((size_t)lane * 2 + slot) * c->log.capacity, (size_t)c->log.capacity * 2))) return rc;
     return d2h(c, start, c->log.start + (size_t)lane * 2 + slot, 16);
+}
+
+int g2048_log_final(g2048_ctx* c, uint32_t lane, uint32_t slot, uint8_t* board) {
+    if (!c || !board) return c ? fail(c, G2048_ERR_ARG, "null buffer") : G2048_ERR_ARG;
+    if (!c->log.lanes) return fail(c, G2048_ERR_STATE, "game log is not enabled");
+    NEED(c, lane < c->log.lanes && slot < 2, "bad lane / slot");
+    if (int rc = bind(c)) return rc;
+    return d2h(c, board, c->log.final + (size_t)lane * 2 + slot, 16);
 }
 
 int g2048_stats_get(g2048_ctx* c, g2048_stats* out) {

@@ -224,6 +224,12 @@ class Engine:
         self._c(self.lib.g2048_log_game(self.ctx, int(lane), int(slot), _buf(moves), _buf(start)))
         return moves, start
 
+    def log_final(self, lane, slot):
+        """uint8[4,4]: the board a finished recorded game ended on."""
+        board = np.empty((4, 4), np.uint8)
+        self._c(self.lib.g2048_log_final(self.ctx, int(lane), int(slot), _buf(board)))
+        return board
+
     def set_lane_sort(self, every):
         """Re-order the lanes by their big-tile pattern every `every` TD steps (0 = never); invisible to the host."""
         self._c(self.lib.g2048_set_lane_sort(self.ctx, int(every)))

@@ -173,6 +173,8 @@ int g2048_get_last_move(g2048_ctx* ctx, uint16_t* out /* [B] */);
 int g2048_log_enable(g2048_ctx* ctx, uint32_t lanes, uint32_t capacity);
 int g2048_log_meta(g2048_ctx* ctx, uint32_t* meta /* [lanes][8] */);
 int g2048_log_game(g2048_ctx* ctx, uint32_t lane, uint32_t slot, uint16_t* moves /* [capacity] */, uint8_t* start /* [16] */);
+/* the board a finished recorded game ended on (Game.row of the game QAgent.episode returns, r_learning.py:252) */
+int g2048_log_final(g2048_ctx* ctx, uint32_t lane, uint32_t slot, uint8_t* board /* [16] */);
 int g2048_stats_get(g2048_ctx* ctx, g2048_stats* out);
 int g2048_stats_reset(g2048_ctx* ctx);
 

@@ -400,7 +400,7 @@ def test_lane_sort_same_games_at_scale():
                 for slot in (0, 1):
                     length, score, flags = int(meta[lane, 3 + 2 * slot]), int(meta[lane, 4 + 2 * slot]), int(meta[lane, 7])
                     if length and not (flags >> slot) & 5 and done < 12:
-                        agent._game_from_log(eng, lane, slot, length, score)      # asserts that the record replays to the score
+                        agent._game_from_log(eng, lane, slot, length, score, verify=True)      # asserts that the record replays to its end
                         done += 1
             assert done >= 8
         eng.close()

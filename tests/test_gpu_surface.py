@@ -177,7 +177,7 @@ def test_device_game_records(api):
             length, score = int(meta[lane, 3 + 2 * slot]), int(meta[lane, 4 + 2 * slot])
             if meta[lane, 2] - seen[lane] > 1 or not length:
                 continue                                       # two games ended in one window: the older one is gone
-            game = agent._game_from_log(eng, int(lane), slot, length, score)      # asserts the replayed score
+            game = agent._game_from_log(eng, int(lane), slot, length, score, verify=True)      # asserts that the record replays to its end
             assert game.odometer == length and game.game_over(game.row)
             finished += 1
         seen[:] = meta[:, 2]
