@@ -10,7 +10,12 @@
 //                                extra copy (see k_td_play)
 //   label   float[B]       4 B   `old_label`
 //   flags   u8[B]                HAS_PREV / DONE
+//   lane_id u32[B]               which lane of the context sits at this position (the lanes are re-ordered by board pattern
+//                                every few steps, LaneSort; the ABI always shows them in lane order)
 //   weights float[slots]         flat n-tuple table, feature-major, weight_signature group order
+// One TD step = k_td_play (all lanes choose and move with the same table) -> k_td_update_owner (the step's records are
+// summed per symmetry orbit by workgroups that own table slices in LDS; n = 6: + k_hex_* for the f_6 orbits) ->
+// k_apply_orbits (orbit sums -> member tables).
 // There is no dense contraction anywhere on this path: no MFMA.  The kernels are integer SWAR + random 4-byte
 // gathers + fp32 atomic adds; what bounds them is the memory system, not the VALU.
 #include <hip/hip_runtime.h>
@@ -1852,7 +1857,7 @@ struct g2048_ctx {
     int cur = 0;                        // which half of `prev` holds the current `state`
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_plan = nullptr;
-    bool plan_pending = false;          // replan_readback queued, replan not yet done
+    bool plan_pending = false;          // stats_readback recorded its event, replan has not looked at the statistics yet
     uint4* boards = nullptr;
     int32_t* scores = nullptr;
     ulonglong2* rng = nullptr;
