@@ -1922,6 +1922,7 @@ struct g2048_ctx {
         int feedback_each_step = 1;     // read the workgroup clocks back after every step (big batches only)
         double add_cost = 3.0, thr = 0.01, fixed_ratio = 0.25;
         int plan_feedback = 1, plan_xcd = 1, debug_plan = 0;
+        int plan_mixed = 1;             // XCD-resident plan: chunks too light for 8 workgroups are scanned flat
         unsigned play_wgs = 0;
         uint32_t play_dynamic = 1;      // full rounds of k_td_play's lane blocks left to the counter (besides the last, partial one)
         uint32_t sort_every = 16;       // default of g2048_set_lane_sort for new contexts (G2048_SORT_EVERY); 0 = never
@@ -2014,6 +2015,7 @@ void read_knobs(g2048_ctx* c) {
     if (const char* e = getenv("G2048_PLAN_THR")) k.thr = atof(e);
     if (const char* e = getenv("G2048_PLAN_FEEDBACK")) k.plan_feedback = atoi(e);
     if (const char* e = getenv("G2048_PLAN_XCD")) k.plan_xcd = atoi(e);
+    if (const char* e = getenv("G2048_PLAN_MIXED")) k.plan_mixed = atoi(e);
     if (getenv("G2048_DEBUG_PLAN")) k.debug_plan = 1;
     if (const char* e = getenv("G2048_PLAY_WGS")) k.play_wgs = (unsigned)atoi(e);
     if (const char* e = getenv("G2048_PLAY_DYNAMIC")) k.play_dynamic = (uint32_t)atoi(e);
@@ -2444,12 +2446,46 @@ int build_slices(g2048_ctx* c) {
         // XCD, so parts come in multiples of 8), and what fits of it stays in that L2 between the ~28 chunk scans instead of
         // every scan of every record going out to the fabric.  The coarser split balances a little worse than the flat
         // plan; with the measured costs it still wins: 0.3005 -> 0.2954 ms per step (n = 5), mean rule 0.400 -> 0.385.
-        for (size_t k = 0; k < nc; ++k) parts[k] = in_lds[k] ? 1 : 0;
-        for (size_t extra = n_lds; extra < CUS_PER_XCD; ++extra) {          // greedy: the slowest workgroup gets help
+        // Chunks too light for 8 workgroups (one per XCD is the finest the XCD-resident split allows) are scanned "flat"
+        // instead: `fparts` workgroups anywhere, each taking every fparts-th record block.  Their scans miss the XCD's L2,
+        // but they are the cheap ones (the centre square's records are 6 B), and the workgroups they give back go where the
+        // makespan is: owner kernel 0.095 -> 0.085 ms at 2^20 lanes, n = 5 (G2048_PLAN_MIXED=0 turns it off).
+        double lds_total = 0;
+        for (size_t k = 0; k < nc; ++k)
+            if (in_lds[k]) lds_total += cost[k];
+        std::vector<uint32_t> fparts(nc, 0);
+        uint32_t flat_wgs = 0, n_xcd = 0;
+        const uint32_t budget = XCDS * CUS_PER_XCD;
+        const uint32_t min_flat = (c->update_rule == 1 && c->knob.mean_one_pass) ? (uint32_t)((4ull * c->B) >> 21) + 1u : 1u;
+        for (size_t k = 0; k < nc; ++k) {
+            if (!in_lds[k]) continue;
+            const double ideal = lds_total > 0 ? cost[k] / lds_total * budget : 8.0;
+            if (c->knob.plan_mixed && ideal < 6.0) {
+                fparts[k] = std::max(min_flat, (uint32_t)(ideal + 0.999));
+                flat_wgs += fparts[k];
+            } else {
+                ++n_xcd;
+            }
+        }
+        if (n_xcd == 0 || flat_wgs + XCDS * n_xcd > budget) {        // (degenerate: fall back to all XCD-resident)
+            std::fill(fparts.begin(), fparts.end(), 0u);
+            flat_wgs = 0;
+            n_xcd = (uint32_t)n_lds;
+        }
+        const uint32_t per_xcd_budget = (budget - flat_wgs) / XCDS;
+        for (size_t k = 0; k < nc; ++k) parts[k] = (in_lds[k] && !fparts[k]) ? 1 : 0;
+        for (size_t extra = n_xcd; extra < per_xcd_budget; ++extra) {       // greedy: the slowest workgroup gets help
             size_t worst = nc;
             for (size_t k = 0; k < nc; ++k)
-                if (in_lds[k] && (worst == nc || cost[k] / parts[k] > cost[worst] / parts[worst])) worst = k;
+                if (parts[k] && (worst == nc || cost[k] / parts[k] > cost[worst] / parts[worst])) worst = k;
             ++parts[worst];
+        }
+        for (uint32_t spare = budget - flat_wgs - XCDS * per_xcd_budget; spare > 0; --spare) {      // what does not make a group of 8
+            size_t worst = nc;
+            for (size_t k = 0; k < nc; ++k)
+                if (fparts[k] && (worst == nc || cost[k] / fparts[k] > cost[worst] / fparts[worst])) worst = k;
+            if (worst == nc) break;
+            ++fparts[worst];
         }
         std::vector<std::pair<size_t, uint32_t>> per_xcd;                   // (chunk, j) of one XCD, longest-running first
         for (size_t k = 0; k < nc; ++k)
@@ -2464,6 +2500,10 @@ int build_slices(g2048_ctx* c) {
                 sl.xcd = 1u;
                 v.push_back(sl);
             }
+        for (size_t k = 0; k < nc; ++k)                                     // the flat ones behind the groups of 8
+            for (uint32_t j = 0; j < fparts[k]; ++j) v.push_back(slice_of(k, j, fparts[k]));
+        for (size_t k = 0; k < nc; ++k)
+            if (fparts[k]) parts[k] = fparts[k];                            // (for the debug print)
     } else {
         // one-pass mean rule: a workgroup's count field must leave the sums enough bits (k_td_update_owner), so no
         // workgroup scans more than 2^21 / 4 records
