@@ -1922,7 +1922,7 @@ struct g2048_ctx {
         int feedback_each_step = 1;     // read the workgroup clocks back after every step (big batches only)
         double add_cost = 3.0, thr = 0.01, fixed_ratio = 0.25;
         int plan_feedback = 1, plan_xcd = 1, debug_plan = 0;
-        int plan_mixed = 1;             // XCD-resident plan: chunks too light for 8 workgroups are scanned flat
+        double plan_mixed = 6.0;        // XCD-resident plan: chunks that deserve fewer workgroups than this are scanned flat (0: none)
         unsigned play_wgs = 0;
         uint32_t play_dynamic = 1;      // full rounds of k_td_play's lane blocks left to the counter (besides the last, partial one)
         uint32_t sort_every = 16;       // default of g2048_set_lane_sort for new contexts (G2048_SORT_EVERY); 0 = never
@@ -2015,7 +2015,7 @@ void read_knobs(g2048_ctx* c) {
     if (const char* e = getenv("G2048_PLAN_THR")) k.thr = atof(e);
     if (const char* e = getenv("G2048_PLAN_FEEDBACK")) k.plan_feedback = atoi(e);
     if (const char* e = getenv("G2048_PLAN_XCD")) k.plan_xcd = atoi(e);
-    if (const char* e = getenv("G2048_PLAN_MIXED")) k.plan_mixed = atoi(e);
+    if (const char* e = getenv("G2048_PLAN_MIXED")) k.plan_mixed = atof(e);
     if (getenv("G2048_DEBUG_PLAN")) k.debug_plan = 1;
     if (const char* e = getenv("G2048_PLAY_WGS")) k.play_wgs = (unsigned)atoi(e);
     if (const char* e = getenv("G2048_PLAY_DYNAMIC")) k.play_dynamic = (uint32_t)atoi(e);
@@ -2460,7 +2460,7 @@ int build_slices(g2048_ctx* c) {
         for (size_t k = 0; k < nc; ++k) {
             if (!in_lds[k]) continue;
             const double ideal = lds_total > 0 ? cost[k] / lds_total * budget : 8.0;
-            if (c->knob.plan_mixed && ideal < 6.0) {
+            if (ideal < c->knob.plan_mixed) {
                 fparts[k] = std::max(min_flat, (uint32_t)(ideal + 0.999));
                 flat_wgs += fparts[k];
             } else {
