@@ -123,8 +123,27 @@ def side_workload(pkg, args):
         out = dict(workload=f'BASELINE config 3: {n}-tuple evaluate + 4-way greedy select, inference only', batch=B,
                    steps=args.steps, value=B * args.steps / (ms * 1e-3), unit='boards/s', ms_per_step=ms / args.steps,
                    algorithmic_GBps=by * B * args.steps / (ms * 1e-3) / 1e9)
-    print(json.dumps(out), flush=True)
+    emit(out)
     eng.close()
+
+
+_RESULT_FD = None
+
+
+def claim_stdout():
+    """The contract is ONE line on stdout.  Libraries print there too (RCCL writes its version banner on communicator
+    creation), so the process's fd 1 is pointed at stderr for the whole run and the result line goes out through a saved
+    duplicate of the original stdout."""
+    global _RESULT_FD
+    if _RESULT_FD is None:
+        sys.stdout.flush()
+        _RESULT_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(out):
+    line = (json.dumps(out) + '\n').encode()
+    os.write(_RESULT_FD if _RESULT_FD is not None else 1, line)
 
 
 def self_launch(args):
@@ -181,6 +200,7 @@ def main():
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         return self_launch(args)
 
+    claim_stdout()
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -354,7 +374,7 @@ def main():
             out['mean_rule'] = mean_line
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(n, args.cpu_seconds)
-        print(json.dumps(out), flush=True)
+        emit(out)
     if isinstance(sync, par.NativeSync):
         sync.close()
     eng.close()
