@@ -633,6 +633,11 @@ __global__ __launch_bounds__(WG) void k_update_records(float* w, float* dacc, co
 //   terminal records      : (this step's afterstate, -V(after) * alpha / F) for lanes whose game ended after the spawn
 //                           (r_learning.py:248) — rare, so they go to a compact queue (one atomic counter bump per wave).
 
+// k_td_play hands the last part of a launch's lane blocks out through counters.  Returning atomics on ONE address complete
+// one after the other (~50 ns each on MI355X: 256 waves asking one counter cost the launch ~12 us per round), so there are
+// 64 counters, each in its own cache line; the workgroups that share one sit on the same XCD (blockIdx % 64 fixes blockIdx % 8).
+constexpr uint32_t PLAY_SEGS = 64, PLAY_SEG_STRIDE = 32;
+
 struct TdRecs {
     const uint4* state1;    // prev[cur]
     float* dw1;             // [B]
@@ -640,8 +645,8 @@ struct TdRecs {
     float* qdw;             // [B]
     uint32_t* qcount;       // length of this step's queue
     uint32_t* qcount_next;  // next step's counter, zeroed by k_td_play
-    uint32_t* blocks;       // [8] k_td_play's work counters (one per XCD segment): the next 64-lane block to hand out
-    uint32_t* blocks_next;  // [8] next step's, zeroed by k_td_play
+    uint32_t* blocks;       // [PLAY_SEGS x PLAY_SEG_STRIDE] k_td_play's work counters (one per segment, a cache line each): the next 64-lane block to hand out
+    uint32_t* blocks_next;  // next step's, zeroed by k_td_play
     uint32_t unit;          // 1: every record counts as dw = 1 (the counting pass of the per-slot mean rule)
     uint32_t* dwmax;        // float bits of the largest |dw| among this step's records (scale of the fixed-point sums)
     uint32_t* dwmax_next;   // next step's, zeroed by k_td_play
@@ -758,6 +763,8 @@ __device__ __forceinline__ void log_step(const GameLog& lg, uint32_t i, uint32_t
 #ifdef G2048_EXP_PHASES      // (experiment build: where a wave of k_td_play spends its time; tools/exp/phases.py)
 __device__ unsigned long long g_phase_ticks[8192 * 4 * 8];    // [workgroup][wave][phase], summed by the host
 __device__ unsigned long long g_wg_span[2 * 8192];
+__device__ unsigned long long g_wg_hw[8192];                  // XCC_ID << 32 | HW_ID of the workgroup's first wave
+__device__ unsigned long long g_wave_info[8192 * 4 * 2];      // per wave: end stamp, blocks processed
 #define PHASE_STAMP(k)                                          \
     do {                                                        \
         const unsigned long long now_ = wall_clock64();         \
@@ -776,17 +783,18 @@ __device__ unsigned long long g_wg_span[2 * 8192];
 #ifndef G2048_PLAY_MIN_WAVES      // (experiment: minimum waves per SIMD the register allocation of k_td_play must allow; 0 = compiler's choice)
 #define G2048_PLAY_MIN_WAVES 0
 #endif
-template <int N, int TPB, bool HOT>
-__global__ __launch_bounds__(TPB, G2048_PLAY_MIN_WAVES) void k_td_play(LaneSet in, LaneSet out, const uint32_t* __restrict__ perm, uint4* prev_nxt,
+template <int N, int TPB, bool HOT, bool PERM>
+__global__ __launch_bounds__(TPB, G2048_PLAY_MIN_WAVES) void k_td_play(LaneSet in, LaneSet out, const uint32_t* __restrict__ perm_, uint4* prev_nxt,
                                                  uint32_t B, const float* __restrict__ w, float alpha, TdRecs recs, int auto_reset,
                                                  Stats* stats, GameLog lg, uint32_t static_rounds) {
     constexpr float F = (float)Shape<N>::F;
+    const uint32_t* const perm = PERM ? perm_ : nullptr;       // (compile-time: a run-time test would put a wait behind every block's first load)
     __shared__ WgStats ws;
     __shared__ float hot[HOT ? HOT_SLOTS : 1];
     wg_stats_init(&ws);
     if constexpr (HOT) load_hot_set<TPB>(hot, w);
-    if (blockIdx.x == 0 && threadIdx.x < 8) {
-        recs.blocks_next[threadIdx.x] = 0;
+    if (blockIdx.x == 0 && threadIdx.x < PLAY_SEGS) {
+        recs.blocks_next[threadIdx.x * PLAY_SEG_STRIDE] = 0;
         if (threadIdx.x == 0) {
             *recs.qcount_next = 0;
             *recs.dwmax_next = 0;
@@ -796,53 +804,107 @@ __global__ __launch_bounds__(TPB, G2048_PLAY_MIN_WAVES) void k_td_play(LaneSet i
     // is left — no barrier anywhere in the loop, the waves of a workgroup run on independently.  The first `static_rounds`
     // blocks of wave v are v, v + V, v + 2V ... (V waves in the grid); the blocks behind them are cut into 8 segments, one
     // per XCD (blockIdx % 8), each handed out through its own counter, which keeps the hardware's balance at the end of the
-    // launch (a wave that is ahead takes more) without thousands of returning atomics on one address.  The counter is read
-    // ONE BLOCK AHEAD: the atomic is issued before the block's loads and stores, so that waiting for it does not wait for
-    // those stores (vmcnt retires in order).
+    // launch (a wave that is ahead takes more) without thousands of returning atomics on one address.
+    // The loop is software-pipelined by one block: while block k is computed, the lane state of block k + 1 is already on
+    // its way (two waves per SIMD do not hide a load round trip in front of every block), so the block index is needed one
+    // block early and the dynamic counter is read TWO blocks ahead (vmcnt retires in order: an atomic issued behind a
+    // block's loads and stores would wait for all of them).
 #ifdef G2048_EXP_PHASES
     unsigned long long phase_t_ = wall_clock64();
     unsigned long long phase_acc_[8] = {};
-    if (threadIdx.x == 0 && blockIdx.x < 8192) g_wg_span[2 * blockIdx.x] = phase_t_;
+    if (threadIdx.x == 0 && blockIdx.x < 8192) {
+        g_wg_span[2 * blockIdx.x] = phase_t_;
+        g_wg_hw[blockIdx.x] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32 | __builtin_amdgcn_s_getreg((31 << 11) | 4);
+    }
+    unsigned long long blocks_done_ = 0;
 #endif
-    constexpr uint32_t WAVES = TPB / 64;
+    constexpr uint32_t WAVES = TPB / 64, NONE = 0xFFFFFFFFu;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t nwaves = gridDim.x * WAVES, wave_id = blockIdx.x * WAVES + (threadIdx.x >> 6);
     const uint32_t nblocks = (B + 63u) / 64u;
     const uint32_t dyn0 = static_rounds * nwaves < nblocks ? static_rounds * nwaves : nblocks;     // first block of the dynamic region
-    const uint32_t nseg = gridDim.x < 8u ? gridDim.x : 8u;         // (a small grid does not reach all 8 XCDs)
+#ifdef G2048_EXP_SEG_XCD        // (experiment: the workgroups that share a counter sit on one XCD)
+    const uint32_t nseg = gridDim.x < PLAY_SEGS ? gridDim.x : PLAY_SEGS;
     const uint32_t seg = blockIdx.x % nseg, seg_len = (nblocks - dyn0 + nseg - 1u) / nseg;
+#else
+    const uint32_t nseg = (gridDim.x + 7u) / 8u < PLAY_SEGS ? (gridDim.x + 7u) / 8u : PLAY_SEGS;
+    const uint32_t seg = (blockIdx.x / 8u) % nseg, seg_len = (nblocks - dyn0 + nseg - 1u) / nseg;
+#endif
     const uint32_t seg_lo = dyn0 + seg * seg_len, seg_hi = seg_lo + seg_len < nblocks ? seg_lo + seg_len : nblocks;
-    uint32_t* const counter = recs.blocks + seg;
+    // The counter's address is made opaque to the compiler: for an atomic on a uniform address it would elect a lane and
+    // broadcast the result with v_readfirstlane behind an s_waitcnt vmcnt(0) right at the atomic — a full round trip, plus
+    // the drain of the previous block's stores, in front of every block (which is what the dynamic rounds used to cost).
+    uint32_t opaque_zero;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(opaque_zero));
+    uint32_t* const counter = recs.blocks + seg * PLAY_SEG_STRIDE + opaque_zero;
     uint32_t ahead = 0, my_moves = 0, my_dirs = 0;
     float dw_big = 0.0f;            // largest |dw| this lane emits in the whole launch
-    if (lane == 0 && static_rounds == 0) ahead = seg_lo + atomicAdd(counter, 1u);
-    for (uint32_t it = 0;; ++it) {
-    uint32_t blk;
-    if (it < static_rounds) {
-        blk = it * nwaves + wave_id;
-        if (lane == 0 && it + 1 == static_rounds) ahead = seg_lo + atomicAdd(counter, 1u);
+
+    // the state a lane carries into a block
+    struct LaneIn {
+        uint32_t src;
+        uint8_t fl;
+        Board b;
+        Rng g;
+        int32_t score;
+        float old_label;
+        uint32_t lid;
+    };
+    // the whole lane state is requested at once: loading the flags first and the rest behind the DONE test would put two
+    // memory round trips in front of every block
+    // (unconditional loads from a clamped index: loads under a branch are merged with the "not loaded" value at its end,
+    // which makes the compiler wait for them right there)
+    auto load_lane = [&](uint32_t blk) {
+        LaneIn L;
+        const uint32_t i = blk * 64u + lane, j = (blk != NONE && i < B) ? i : 0u;
+        L.src = perm ? perm[j] : j;
+        L.fl = in.flags[L.src];
+        L.b = ld_board(in.boards, L.src);
+        L.g = ld_rng(in.rng, L.src);
+        L.score = in.scores[L.src];
+        L.old_label = in.label[L.src];
+        const uint32_t id = in.lane_id[L.src];          // (always loaded: a load under a run-time test is waited for at the test's end)
+        L.lid = (PERM || lg.lanes) ? id : i;
+        return L;
+    };
+    uint32_t blk;                   // the block being computed
+    if (static_rounds > 0) {
+        blk = wave_id;
     } else {
-        blk = (uint32_t)__builtin_amdgcn_readfirstlane((int)ahead);
-        if (blk >= seg_hi) break;
-        if (lane == 0) ahead = seg_lo + atomicAdd(counter, 1u);
+        if (lane == 0) ahead = atomicAdd(counter, 1u);
+        blk = seg_lo + (uint32_t)__builtin_amdgcn_readfirstlane((int)ahead);
+        if (blk >= seg_hi) blk = NONE;
     }
-    if (blk >= nblocks) break;
+    if (static_rounds <= 1 && lane == 0) ahead = atomicAdd(counter, 1u);        // the second block comes from the counter
+    // the block behind block number `it` of this wave (and, two blocks ahead, the request to the counter)
+    auto block_after = [&](uint32_t it) {
+        uint32_t nxt;
+        if (it + 1 < static_rounds) {
+            nxt = (it + 1) * nwaves + wave_id;
+        } else {
+            nxt = seg_lo + (uint32_t)__builtin_amdgcn_readfirstlane((int)ahead);      // (seg_lo is added here, not at the atomic: an
+            if (nxt >= seg_hi) nxt = NONE;                                              // instruction that consumes its result makes the wave wait for it there)
+        }
+        if (it + 2 >= static_rounds && lane == 0) ahead = atomicAdd(counter, 1u);
+        return nxt;
+    };
+    auto process = [&](const uint32_t blk, const LaneIn& cur) __attribute__((always_inline)) {
     PHASE_STAMP(0);             // block hand-out
+#ifdef G2048_EXP_PHASES
+    ++blocks_done_;
+#endif
     const uint32_t i = blk * 64u + lane;
 
     bool moved = false;
     uint32_t ndirs = 0;             // directions that were open to this lane's move
     if (i < B) {
-        const uint32_t src = perm ? perm[i] : i;
-        // the whole lane state is requested at once: loading the flags first and the rest behind the DONE test would put two
-        // memory round trips in front of every block
-        uint8_t fl = in.flags[src];
-        Board b = ld_board(in.boards, src);
-        Rng g = ld_rng(in.rng, src);
-        int32_t score = in.scores[src];
-        float old_label = in.label[src];
-        uint32_t lid = i;
-        if (perm || lg.lanes) lid = in.lane_id[src];
+        const uint32_t src = cur.src;
+        uint8_t fl = cur.fl;
+        Board b = cur.b;
+        Rng g = cur.g;
+        int32_t score = cur.score;
+        float old_label = cur.old_label;
+        const uint32_t lid = cur.lid;
         if (perm) out.lane_id[i] = lid;
         float dw1 = 0.0f;
         uint32_t lm = 0;        // what this lane did: bits 0-1 direction, 2 moved, 4-7 new tile's cell, 8-9 new tile, 10 spawned, 11 game ended
@@ -953,6 +1015,31 @@ __global__ __launch_bounds__(TPB, G2048_PLAY_MIN_WAVES) void k_td_play(LaneSet i
     my_moves += moved ? 1u : 0u;
     my_dirs += ndirs;
     PHASE_STAMP(4);
+    };
+    // two copies of the body with the roles of the two state sets swapped: with one copy the prefetched state would have to
+    // be moved into the current one's registers at the end of every block, behind a wait for the block's own stores
+#ifdef G2048_EXP_NOPIPE          // (experiment: the same loop without the state prefetch)
+    for (uint32_t it = 0; blk != NONE; ++it) {
+        const uint32_t nb = block_after(it);
+        const LaneIn st = load_lane(blk);
+        process(blk, st);
+        blk = nb;
+    }
+    if (false) {
+#else
+    if (blk != NONE) {
+#endif
+        LaneIn sa = load_lane(blk), sb;
+        for (uint32_t it = 0;; it += 2) {
+            const uint32_t nb = block_after(it);
+            sb = load_lane(nb);
+            process(blk, sa);
+            if (nb == NONE) break;
+            blk = block_after(it + 1);
+            sa = load_lane(blk);
+            process(nb, sb);
+            if (blk == NONE) break;
+        }
     }
     // the wave reductions happen once per launch, not once per block (they cost 2.4 us of a block's 22 there)
     if (dw_big > 0.0f) atomicMax(&ws.dw_max_bits, __float_as_uint(dw_big));
@@ -961,8 +1048,11 @@ __global__ __launch_bounds__(TPB, G2048_PLAY_MIN_WAVES) void k_td_play(LaneSet i
     if (threadIdx.x == 0 && ws.dw_max_bits) atomicMax(recs.dwmax, ws.dw_max_bits);
 #ifdef G2048_EXP_PHASES
     PHASE_STAMP(5);             // leaving the loop, statistics flush
-    if ((threadIdx.x & 63) == 0 && blockIdx.x < 8192 && threadIdx.x < 256)
-        for (int k = 0; k < 8; ++k) g_phase_ticks[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + k] += phase_acc_[k];
+    if ((threadIdx.x & 63) == 0 && wave_id < 8192 * 4) {
+        for (int k = 0; k < 8; ++k) g_phase_ticks[(size_t)wave_id * 8 + k] += phase_acc_[k];
+        g_wave_info[(size_t)wave_id * 2] = phase_t_;
+        g_wave_info[(size_t)wave_id * 2 + 1] = blocks_done_;
+    }
     if (threadIdx.x == 0 && blockIdx.x < 8192) g_wg_span[2 * blockIdx.x + 1] = wall_clock64();
 #endif
 }
@@ -1846,6 +1936,8 @@ __global__ __launch_bounds__(WG) void k_delta_add_mean(float* w, float* w0, cons
 
 }  // namespace
 
+constexpr size_t QCOUNT_WORDS = 32 + 2 * PLAY_SEGS * PLAY_SEG_STRIDE;
+
 // ================================================================================================ host side / C ABI
 
 struct g2048_ctx {
@@ -1875,7 +1967,7 @@ struct g2048_ctx {
     float* dw1 = nullptr;               // main record of every lane (0 = none)
     uint4* qstate = nullptr;            // terminal-record queue
     float* qdw = nullptr;
-    uint32_t* qcount = nullptr;         // [32]: this / next step's queue length [0,1], largest |dw| bits [2,3], k_td_play's 8 block counters [8..15], [16..23]
+    uint32_t* qcount = nullptr;         // [QCOUNT_WORDS]: this / next step's queue length [0,1], largest |dw| bits [2,3], from [32] on k_td_play's block counters (two sets)
     uint16_t* last_move = nullptr;      // what every lane did in the latest TD step (g2048_get_last_move)
     // lane order (LaneSort): boards / scores / rng / label / flags / last_move / lane_id above are the CURRENT set; `alt` is
     // the other one (allocated with the first re-ordering)
@@ -1884,6 +1976,13 @@ struct g2048_ctx {
     bool permuted = false;              // the lanes are not in identity order
     uint32_t sort_every = 0;            // re-order the lanes every this many TD steps (0 = never)
     uint32_t steps_since_sort = 0;
+    // the sort itself runs on a side stream beside the following steps' kernels; its permutation is applied `sort_lag` steps
+    // after the boards it was computed from (lanes keep their positions in between, so a stale order is still a valid one)
+    hipStream_t sort_stream = nullptr;
+    hipEvent_t ev_sort_go = nullptr, ev_sort_done = nullptr;
+    bool sort_pending = false;          // sort_perm is being (or has been) computed and waits to be applied
+    bool sort_issued = false;           // ev_sort_done has been recorded at least once
+    uint32_t sort_wait = 0;             // steps until the pending permutation is applied
     uint64_t *sort_keys = nullptr, *sort_keys_out = nullptr;
     uint32_t *sort_iota = nullptr, *sort_perm = nullptr;
     void* sort_temp = nullptr;
@@ -1924,9 +2023,10 @@ struct g2048_ctx {
         int plan_feedback = 1, plan_xcd = 1, debug_plan = 0;
         double plan_mixed = 6.0;        // XCD-resident plan: chunks that deserve fewer workgroups than this are scanned flat (0: none)
         unsigned play_wgs = 0;
-        uint32_t play_dynamic = 1;      // full rounds of k_td_play's lane blocks left to the counter (besides the last, partial one)
+        uint32_t play_dynamic = 2;      // full rounds of k_td_play's lane blocks left to the counter (besides the last, partial one)
         uint32_t sort_every = 16;       // default of g2048_set_lane_sort for new contexts (G2048_SORT_EVERY); 0 = never
         uint32_t sort_min_batch = 1u << 17;     // smaller batches keep their lane order
+        uint32_t sort_lag = 2;          // steps between the boards a sort looks at and the step that applies it (G2048_SORT_LAG; 0 = sort in line)
         int hex_bins = 1;               // n = 6: f_6 orbits through k_hex_* (0: k_td_update_tail's scattered atomics)
         int mean_one_pass = 1;          // per-slot mean rule: counts packed beside the sums (0: always two accumulation passes)
         int play_hot = 0;               // 1: k_td_play reads the hot four-cell tuples from an LDS copy (n >= 4, big batches); measured, not faster
@@ -2024,6 +2124,7 @@ void read_knobs(g2048_ctx* c) {
     if (const char* e = getenv("G2048_HEX_BINS")) k.hex_bins = atoi(e);
     if (const char* e = getenv("G2048_SORT_EVERY")) k.sort_every = (uint32_t)atoi(e);
     if (const char* e = getenv("G2048_SORT_MIN")) k.sort_min_batch = (uint32_t)atoi(e);
+    if (const char* e = getenv("G2048_SORT_LAG")) k.sort_lag = (uint32_t)atoi(e);
     if (const char* e = getenv("G2048_PLAY_HOT_MIN")) k.play_hot_min = (uint32_t)atoi(e);
 }
 
@@ -2092,16 +2193,32 @@ int lane_sort_prepare(g2048_ctx* c) {
     hipError_t e = hipMalloc(&c->sort_temp, bytes ? bytes : 16);
     if (e != hipSuccess) return fail(c, G2048_ERR_NOMEM, "hipMalloc(sort scratch)", e);
     c->sort_temp_bytes = bytes;
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->sort_stream, hipStreamNonBlocking));
+    HIP_TRY(c, hipEventCreateWithFlags(&c->ev_sort_go, hipEventDisableTiming));
+    HIP_TRY(c, hipEventCreateWithFlags(&c->ev_sort_done, hipEventDisableTiming));
     return G2048_OK;
 }
 
-// keys of the current boards -> sort_perm: position i of the new order takes the lane now at position sort_perm[i]
-int lane_sort_permutation(g2048_ctx* c) {
+// keys of the current boards -> sort_perm: position i of the new order takes the lane now at position sort_perm[i].
+// `side`: the keys are taken on the context's stream (the boards as they are now), the sort runs on the side stream and
+// ev_sort_done marks its end; otherwise everything is queued in line.
+int lane_sort_permutation(g2048_ctx* c, bool side) {
     if (int rc = lane_sort_prepare(c)) return rc;
+    if (c->sort_issued) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_sort_done, 0));       // (an abandoned sort may still be reading the key buffer)
     k_sort_keys<<<grid_for(c->B), WG, 0, c->stream>>>(c->boards, c->B, c->sort_keys);
+    hipStream_t st = c->stream;
+    if (side) {
+        HIP_TRY(c, hipEventRecord(c->ev_sort_go, c->stream));
+        HIP_TRY(c, hipStreamWaitEvent(c->sort_stream, c->ev_sort_go, 0));
+        st = c->sort_stream;
+    }
     size_t bytes = c->sort_temp_bytes;
-    if (g2048_lane_sort_pairs(c->sort_temp, &bytes, c->sort_keys, c->sort_keys_out, c->sort_iota, c->sort_perm, c->B, 0, SORT_KEY_BITS, c->stream) != 0)
+    if (g2048_lane_sort_pairs(c->sort_temp, &bytes, c->sort_keys, c->sort_keys_out, c->sort_iota, c->sort_perm, c->B, 0, SORT_KEY_BITS, st) != 0)
         return fail(c, G2048_ERR_HIP, "radix sort failed");
+    if (side) {
+        HIP_TRY(c, hipEventRecord(c->ev_sort_done, c->sort_stream));
+        c->sort_issued = true;
+    }
     return G2048_OK;
 }
 
@@ -2121,6 +2238,7 @@ int ensure_identity(g2048_ctx* c) {
     c->cur ^= 1;                    // the carried state now lives in the other half of prev / oidx
     c->permuted = false;
     c->steps_since_sort = 0;
+    c->sort_pending = false;        // a permutation computed for the old positions must not be applied to the new ones
     return launched(c, "k_restore_order");
 }
 #define NEED_IDENTITY(c)                     \
@@ -2620,7 +2738,7 @@ template <int N, int TPB, bool HOT>
 unsigned play_grid(g2048_ctx* c) {
     if (!c->play_wgs) {
         int per_cu = 0, cus = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_td_play<N, TPB, HOT>, TPB, 0) != hipSuccess || per_cu <= 0) per_cu = HOT ? 1 : 2;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_td_play<N, TPB, HOT, false>, TPB, 0) != hipSuccess || per_cu <= 0) per_cu = HOT ? 1 : 2;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || cus <= 0) cus = 256;
         c->play_wgs = (unsigned)(per_cu * cus);
         if (c->knob.play_wgs) c->play_wgs = c->knob.play_wgs;                                 // (experiments)
@@ -2652,8 +2770,8 @@ int launch_td_step(g2048_ctx* c, float alpha, hipEvent_t ev = nullptr, hipEvent_
     recs.qcount_next = c->qcount + (c->step_parity ^ 1u);
     recs.dwmax = c->qcount + 2 + c->step_parity;
     recs.dwmax_next = c->qcount + 2 + (c->step_parity ^ 1u);
-    recs.blocks = c->qcount + 8 + 8 * c->step_parity;
-    recs.blocks_next = c->qcount + 8 + 8 * (c->step_parity ^ 1u);
+    recs.blocks = c->qcount + 32 + PLAY_SEGS * PLAY_SEG_STRIDE * c->step_parity;
+    recs.blocks_next = c->qcount + 32 + PLAY_SEGS * PLAY_SEG_STRIDE * (c->step_parity ^ 1u);
     recs.unit = 0;
     recs.oidx = c->oidx[c->cur];
     recs.oidx_nxt = c->oidx[c->cur ^ 1];
@@ -2665,14 +2783,29 @@ int launch_td_step(g2048_ctx* c, float alpha, hipEvent_t ev = nullptr, hipEvent_
     // lane re-ordering (LaneSort): when due, this step's k_td_play reads the lanes through the sorted permutation
     const uint32_t* perm = nullptr;
     LaneSet lin = current_set(c), lout = lin;
-    if (c->sort_every && c->n >= 4 && B >= c->knob.sort_min_batch && ++c->steps_since_sort >= c->sort_every) {
-        if (int rc = lane_sort_permutation(c)) return rc;
-        perm = c->sort_perm;
-        lout = c->alt;
+    bool start_sort = false;            // take the keys behind this step's k_td_play and sort them on the side stream
+    if (c->sort_every && c->n >= 4 && B >= c->knob.sort_min_batch) {
+        if (c->sort_pending) {
+            if (c->sort_wait == 0 || --c->sort_wait == 0) {
+                HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_sort_done, 0));
+                c->sort_pending = false;
+                perm = c->sort_perm;
+                lout = c->alt;
+            }
+        } else if (++c->steps_since_sort >= c->sort_every) {
+            if (c->knob.sort_lag == 0) {
+                if (int rc = lane_sort_permutation(c, false)) return rc;
+                perm = c->sort_perm;
+                lout = c->alt;
+            } else {
+                start_sort = true;
+            }
+        }
     }
-#define G2048_PLAY(NN, TPB, HOT)                                                                                                      \
-    k_td_play<NN, TPB, HOT><<<play_grid<NN, TPB, HOT>(c), TPB, 0, c->stream>>>(lin, lout, perm, pn, B, c->w, alpha, recs, c->auto_reset, c->stats, c->log, \
-                                                                                play_static_rounds(c, play_grid<NN, TPB, HOT>(c), TPB))
+#define G2048_PLAY_(NN, TPB, HOT, PERM)                                                                                               \
+    k_td_play<NN, TPB, HOT, PERM><<<play_grid<NN, TPB, HOT>(c), TPB, 0, c->stream>>>(lin, lout, perm, pn, B, c->w, alpha, recs, c->auto_reset, c->stats, c->log, \
+                                                                                      play_static_rounds(c, play_grid<NN, TPB, HOT>(c), TPB))
+#define G2048_PLAY(NN, TPB, HOT) (perm ? (G2048_PLAY_(NN, TPB, HOT, true)) : (G2048_PLAY_(NN, TPB, HOT, false)))
     if (play_hot(c)) {
         switch (c->n) {
             case 4: G2048_PLAY(4, PLAY_HOT_WG, true); break;
@@ -2683,10 +2816,17 @@ int launch_td_step(g2048_ctx* c, float alpha, hipEvent_t ev = nullptr, hipEvent_
         BY_N(c, (G2048_PLAY(N, 256, false)));
     }
 #undef G2048_PLAY
+#undef G2048_PLAY_
     if (perm) {
         adopt_set(c, lout);
         c->alt = lin;
         c->permuted = true;
+        c->steps_since_sort = 0;
+    }
+    if (start_sort) {
+        if (int rc = lane_sort_permutation(c, true)) return rc;
+        c->sort_pending = true;
+        c->sort_wait = c->knob.sort_lag;
         c->steps_since_sort = 0;
     }
     if (ev) (void)hipEventRecord(ev, c->stream);
@@ -2833,6 +2973,7 @@ int g2048_destroy(g2048_ctx* c) {
     if (!c) return G2048_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->sort_stream) (void)hipStreamSynchronize(c->sort_stream);
     if (c->comm) (void)g2048_comm_destroy(c);
     if (c->parent) {            // the stream is drained: nothing of this context is pending on the shared table
         if (c->parent->shared_users) --c->parent->shared_users;
@@ -2851,6 +2992,9 @@ int g2048_destroy(g2048_ctx* c) {
     if (c->ev_plan) (void)hipEventDestroy(c->ev_plan);
     if (c->ev_table) (void)hipEventDestroy(c->ev_table);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->ev_sort_go) (void)hipEventDestroy(c->ev_sort_go);
+    if (c->ev_sort_done) (void)hipEventDestroy(c->ev_sort_done);
+    if (c->sort_stream) (void)hipStreamDestroy(c->sort_stream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return G2048_OK;
@@ -2894,7 +3038,7 @@ static int create_impl(int device, uint32_t batch, int n_tuple, uint64_t seed, u
     if ((rc = dalloc(c, &c->boards, B)) || (rc = dalloc(c, &c->scores, B)) || (rc = dalloc(c, &c->rng, B)) ||
         (rc = dalloc(c, &c->prev[0], B)) || (rc = dalloc(c, &c->prev[1], B)) || (rc = dalloc(c, &c->label, B)) ||
         (rc = dalloc(c, &c->flags, B)) || (rc = dalloc(c, &c->dw1, B)) || (rc = dalloc(c, &c->qstate, B)) || (rc = dalloc(c, &c->qdw, B)) ||
-        (rc = dalloc(c, &c->qcount, 32)) || (rc = dalloc(c, &c->last_move, B)) || (rc = dalloc(c, &c->lane_id, B)) ||
+        (rc = dalloc(c, &c->qcount, QCOUNT_WORDS)) || (rc = dalloc(c, &c->last_move, B)) || (rc = dalloc(c, &c->lane_id, B)) ||
         (rc = dalloc(c, &c->stats, 1)))
         return bail(rc);
     if (n_tuple >= 4 && ((rc = dalloc(c, &c->oidx[0], OIDX_BYTES_PER_LANE * B)) || (rc = dalloc(c, &c->oidx[1], OIDX_BYTES_PER_LANE * B)))) return bail(rc);
@@ -2914,7 +3058,7 @@ static int create_impl(int device, uint32_t batch, int n_tuple, uint64_t seed, u
     if (hipMemsetAsync(c->stats, 0, sizeof(Stats), c->stream) != hipSuccess ||
         hipMemsetAsync(c->prev[0], 0, B * sizeof(uint4), c->stream) != hipSuccess ||
         hipMemsetAsync(c->prev[1], 0, B * sizeof(uint4), c->stream) != hipSuccess ||
-        hipMemsetAsync(c->qcount, 0, 128, c->stream) != hipSuccess || hipMemsetAsync(c->last_move, 0, B * 2, c->stream) != hipSuccess || hipMemsetAsync(c->dw1, 0, B * 4, c->stream) != hipSuccess ||
+        hipMemsetAsync(c->qcount, 0, QCOUNT_WORDS * 4, c->stream) != hipSuccess || hipMemsetAsync(c->last_move, 0, B * 2, c->stream) != hipSuccess || hipMemsetAsync(c->dw1, 0, B * 4, c->stream) != hipSuccess ||
         (slots && !parent && hipMemsetAsync(c->w, 0, slots * sizeof(float), c->stream) != hipSuccess))
         return bail(G2048_ERR_HIP);
     k_iota<<<grid_for(B), WG, 0, c->stream>>>(c->lane_id, batch);
@@ -3248,6 +3392,7 @@ int g2048_set_lane_sort(g2048_ctx* c, uint32_t every) {
     if (!c) return G2048_ERR_ARG;
     c->sort_every = every;
     c->steps_since_sort = 0;
+    c->sort_pending = false;
     return G2048_OK;
 }
 
@@ -3356,6 +3501,14 @@ int g2048_debug_phases(unsigned long long* out8, unsigned long long* spans, int 
         std::fill(all.begin(), all.end(), 0ull);
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase_ticks), all.data(), all.size() * 8) != hipSuccess) return G2048_ERR_HIP;
     }
+    return G2048_OK;
+}
+#endif
+
+#ifdef G2048_EXP_PHASES
+int g2048_debug_phases_hw(unsigned long long* hw, unsigned long long* wave) {
+    if (hipMemcpyFromSymbol(hw, HIP_SYMBOL(g_wg_hw), 8192 * 8) != hipSuccess) return G2048_ERR_HIP;
+    if (hipMemcpyFromSymbol(wave, HIP_SYMBOL(g_wave_info), 8192 * 4 * 2 * 8) != hipSuccess) return G2048_ERR_HIP;
     return G2048_OK;
 }
 #endif
