@@ -32,6 +32,25 @@ constexpr uint32_t CROSS_BASE = 17u * 65536u;                   // 4 five-cell f
 constexpr uint32_t HEX_BASE = CROSS_BASE + 4u * 1048576u;       // 12 six-cell base-14 features
 constexpr uint32_t HEX_SIZE = 7529536u;                         // 14^6
 
+// ---- where a table entry lives in device memory (n >= 4, the four- and five-cell tables)
+// A board's index into a four-cell table is four nibbles, and tiles are small: bits 2 and 3 of a nibble hardly vary.  In
+// index order a 128-byte cache line holds one cell's whole nibble plus one bit of the next, so the entries a batch of boards
+// reads are spread thinly over many lines, and — the tables being 256 KB apart — the busy lines of all 17 tables fall on
+// the same few cache sets and L2 channels.  In memory the low 16 index bits are therefore stored 4 x 4 bit-TRANSPOSED
+// ([bit 3 of the four cells | bit 2 .. | bit 1 .. | bit 0 ..]: a line now holds the entries that differ in the cells' low
+// bits), and bits 5..10 are rotated by a per-table constant.  Both steps are bijections of a 65 536-entry block, so every
+// consumer of the table goes through table_place(); the ABI (g2048_weights_get / _set, the delta buffers, feature
+// indices) stays in the reference's order.  Measured: k_td_play 0.168 -> 0.145 ms.
+G2048_HD uint32_t table_place(uint32_t slot) {
+    uint32_t x = slot & 0xFFFFu;
+    uint32_t t = (x ^ (x >> 3)) & 0x0A0Au;
+    x ^= t ^ (t << 3);
+    t = (x ^ (x >> 6)) & 0x00CCu;
+    x ^= t ^ (t << 6);
+    x ^= ((slot >> 16) * 0x9E5u) & 0x07E0u;
+    return (slot & ~0xFFFFu) | x;
+}
+
 G2048_HD uint32_t pack16(uint32_t w) {      // bytes b0..b3 (cells 0..3 of a line) -> b0<<12|b1<<8|b2<<4|b3
     return ((w & 0xFu) << 12) | ((w >> 8 & 0xFu) << 8) | ((w >> 16 & 0xFu) << 4) | (w >> 24 & 0xFu);
 }

@@ -325,10 +325,18 @@ __global__ __launch_bounds__(WG) void k_features(const uint4* boards, uint32_t B
 // One table entry.  (Forcing the scalar-base + 32-bit-vector-offset form of global_load — an opaque 32-bit byte offset,
 // so that a pending gather holds one address register instead of a 64-bit pair — was measured: same register count after
 // allocation, k_td_play 0.200 -> 0.210 ms.  Plain indexing it is.)
+// feature f's slot -> its place in memory (table_place: n >= 4, features 0..20; the f_6 tables and n = 2, 3 are in index order)
+template <int N>
+__device__ __forceinline__ uint32_t place(uint32_t slot, int f) {
+    if constexpr (N < 4) return slot;
+    return f < 21 ? table_place(slot) : slot;
+}
 #ifdef G2048_EXP_NOGATHER        // (experiment: what k_td_play costs without its table reads)
-__device__ __forceinline__ float ld_w(const float* __restrict__ w, uint32_t slot) { return __uint_as_float(0x30000000u | (slot & 0xFFFFu)); }
+template <int N>
+__device__ __forceinline__ float ld_w(const float* __restrict__ w, uint32_t slot, int f) { return __uint_as_float(0x30000000u | (slot & 0xFFFFu)); }
 #else
-__device__ __forceinline__ float ld_w(const float* __restrict__ w, uint32_t slot) { return w[slot]; }
+template <int N>
+__device__ __forceinline__ float ld_w(const float* __restrict__ w, uint32_t slot, int f) { return w[place<N>(slot, f)]; }
 #endif
 
 template <int N>
@@ -338,7 +346,7 @@ __device__ __forceinline__ float value_of(const float* __restrict__ w, const Boa
     feature_slots<N>(pack_board(b), s);
     float x[F];
 #pragma unroll
-    for (int f = 0; f < F; ++f) x[f] = ld_w(w, s[f]);
+    for (int f = 0; f < F; ++f) x[f] = ld_w<N>(w, s[f], f);
     float v = 0.0f;
 #pragma unroll
     for (int f = 0; f < F; ++f) v += x[f];
@@ -387,10 +395,10 @@ __device__ __forceinline__ Choice choose(const float* __restrict__ w, const Move
         float x0[F], x1[F], x2[F], x3[F];
 #pragma unroll
         for (int f = 0; f < F; ++f) {
-            x0[f] = ld_w(w, mv.m0.changed ? s0[f] : 0u);
-            x1[f] = ld_w(w, mv.m1.changed ? s1[f] : 0u);
-            x2[f] = ld_w(w, mv.m2.changed ? s2[f] : 0u);
-            x3[f] = ld_w(w, mv.m3.changed ? s3[f] : 0u);
+            x0[f] = ld_w<N>(w, mv.m0.changed ? s0[f] : 0u, f);
+            x1[f] = ld_w<N>(w, mv.m1.changed ? s1[f] : 0u, f);
+            x2[f] = ld_w<N>(w, mv.m2.changed ? s2[f] : 0u, f);
+            x3[f] = ld_w<N>(w, mv.m3.changed ? s3[f] : 0u, f);
         }
         float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f, v3 = 0.0f;      // each a left-to-right sum, as QAgent.evaluate
 #pragma unroll
@@ -423,8 +431,8 @@ __device__ __forceinline__ Choice choose(const float* __restrict__ w, const Move
         feature_slots<N>(pack_board((MB).after), sb);                                \
         float xa[F], xb[F];                                                          \
         _Pragma("unroll") for (int f = 0; f < F; ++f) {                              \
-            xa[f] = ld_w(w, (MA).changed ? sa[f] : 0u);                              \
-            xb[f] = ld_w(w, (MB).changed ? sb[f] : 0u);                              \
+            xa[f] = ld_w<N>(w, (MA).changed ? sa[f] : 0u, f);                              \
+            xb[f] = ld_w<N>(w, (MB).changed ? sb[f] : 0u, f);                              \
         }                                                                            \
         float va = 0.0f, vb = 0.0f;                                                  \
         _Pragma("unroll") for (int f = 0; f < F; ++f) {                              \
@@ -495,7 +503,7 @@ template <int TPB>
 __device__ __forceinline__ void load_hot_set(float* hot, const float* __restrict__ w) {
     for (uint32_t j = threadIdx.x; j < HOT_SLOTS; j += TPB) {
         const uint32_t f = j / HOT_PER_FEATURE, k = j - f * HOT_PER_FEATURE;
-        hot[j] = w[f * 65536u + expand6(k)];
+        hot[j] = w[table_place(f * 65536u + expand6(k))];
     }
     __syncthreads();
 }
@@ -505,7 +513,7 @@ __device__ __forceinline__ void load_hot_set(float* hot, const float* __restrict
 __device__ __forceinline__ float ld_quad(const float* __restrict__ w, const float* hot, uint32_t f, uint32_t slot, bool use) {
     const uint32_t idx = slot & 0xFFFFu;
     const bool h = hot4(idx);
-    const float* p = h ? hot + (f * HOT_PER_FEATURE + compact6(idx)) : w + slot;
+    const float* p = h ? hot + (f * HOT_PER_FEATURE + compact6(idx)) : w + table_place(slot);
     p = use ? p : hot;                  // directions that do not change the board read one fixed LDS word
     return *p;
 }
@@ -525,7 +533,7 @@ __device__ __forceinline__ Choice choose_hot(const float* __restrict__ w, const 
         uint32_t s[F];                                                                      \
         feature_slots<N>(pack_board((M).after), s);                                         \
         _Pragma("unroll") for (int f = 0; f < 17; ++f) X[f] = ld_quad(w, hot, (uint32_t)f, s[f], (M).changed); \
-        _Pragma("unroll") for (int f = 17; f < F; ++f) X[f] = ld_w(w, (M).changed ? s[f] : 0u);                \
+        _Pragma("unroll") for (int f = 17; f < F; ++f) X[f] = ld_w<N>(w, (M).changed ? s[f] : 0u, f);                \
     }
     if constexpr (F <= G2048_BATCH4_MAXF) {
         G2048_HOT_DIR(mv.m0, x0)
@@ -610,6 +618,8 @@ __device__ __forceinline__ void scatter_image(float* w, float* dacc, const Packe
     constexpr int F = Shape<N>::F;
     uint32_t s[F];
     feature_slots<N>(d4_image(state, g), s);
+#pragma unroll
+    for (int f = 0; f < F; ++f) s[f] = place<N>(s[f], f);
 #pragma unroll
     for (int f = 0; f < F; ++f) __hip_atomic_fetch_add(&w[s[f]], dw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (dacc) {
@@ -820,7 +830,9 @@ __global__ __launch_bounds__(TPB, G2048_PLAY_MIN_WAVES) void k_td_play(LaneSet i
 #endif
     constexpr uint32_t WAVES = TPB / 64, NONE = 0xFFFFFFFFu;
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t nwaves = gridDim.x * WAVES, wave_id = blockIdx.x * WAVES + (threadIdx.x >> 6);
+    // (wave-uniform by construction; readfirstlane tells the compiler, so that block numbers live in SGPRs and the loop's
+    // exits are scalar branches)
+    const uint32_t nwaves = gridDim.x * WAVES, wave_id = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * WAVES + (threadIdx.x >> 6)));
     const uint32_t nblocks = (B + 63u) / 64u;
     const uint32_t dyn0 = static_rounds * nwaves < nblocks ? static_rounds * nwaves : nblocks;     // first block of the dynamic region
 #ifdef G2048_EXP_SEG_XCD        // (experiment: the workgroups that share a counter sit on one XCD)
@@ -889,6 +901,11 @@ __global__ __launch_bounds__(TPB, G2048_PLAY_MIN_WAVES) void k_td_play(LaneSet i
         return nxt;
     };
     auto process = [&](const uint32_t blk, const LaneIn& cur) __attribute__((always_inline)) {
+    // every loaded register is "used" here on all paths: a wave whose lanes skip the block (past the batch, finished games)
+    // would otherwise carry unwaited loads to the loop head, where the compiler then drains the whole memory queue — the
+    // block's own stores included — before it reuses their registers
+    asm volatile("" ::"v"((uint32_t)cur.fl), "v"(cur.b.r[0]), "v"(cur.b.r[1]), "v"(cur.b.r[2]), "v"(cur.b.r[3]), "v"(cur.g.s0), "v"(cur.g.s1), "v"(cur.score),
+                 "v"(cur.old_label), "v"(cur.lid));
     PHASE_STAMP(0);             // block hand-out
 #ifdef G2048_EXP_PHASES
     ++blocks_done_;
@@ -1433,7 +1450,8 @@ __device__ __forceinline__ void mirror_stats(const StatMirror& m) {
 // table_i[perm_i(k)] += v for every member i of the orbit; `dacc` (may be null) mirrors the add (g2048_delta_begin)
 __device__ __forceinline__ void add_to_members(float* w, float* dacc, const OrbitInfo& oi, uint32_t k, float v) {
     for (uint32_t m = 0; m < oi.nmem; ++m) {
-        const uint32_t slot = oi.off[m] + permute_digits(k, oi.perm[m], oi.digits, oi.radix);
+        uint32_t slot = oi.off[m] + permute_digits(k, oi.perm[m], oi.digits, oi.radix);
+        if (slot < HEX_BASE) slot = table_place(slot);
         w[slot] += v;
         if (dacc) dacc[slot] += v;
     }
@@ -1882,13 +1900,14 @@ __global__ __launch_bounds__(WG) void k_restore_order(LaneSet in, LaneSet out, C
 }
 
 // init_weights (r_learning.py:139-149): U[0, scale) per slot, counter-based so any rank can build the same table
-__global__ __launch_bounds__(WG) void k_weights_init(float* w, uint64_t count, uint64_t seed, float scale) {
+// (`placed`: the leading slots that live at table_place())
+__global__ __launch_bounds__(WG) void k_weights_init(float* w, uint64_t count, uint64_t placed, uint64_t seed, float scale) {
     uint64_t i = (uint64_t)blockIdx.x * WG + threadIdx.x;
     uint64_t stride = (uint64_t)gridDim.x * WG;
     for (; i < count; i += stride) {
         uint64_t x = seed + i;
         uint64_t z = splitmix64(x);
-        w[i] = (float)(z >> 40) * (1.0f / 16777216.0f) * scale;
+        w[i < placed ? table_place((uint32_t)i) : i] = (float)(z >> 40) * (1.0f / 16777216.0f) * scale;
     }
 }
 
@@ -1899,38 +1918,49 @@ __global__ __launch_bounds__(WG) void k_delta_sub(const float* w, const float* w
 }
 
 // W = W0 + (delta summed over the ranks); the next epoch starts here: W0 = W, accumulator cleared
-__global__ __launch_bounds__(WG) void k_delta_add(float* w, float* w0, const float* delta, float* dacc, uint64_t count) {
+// In the kernels below the table-side arrays (w, w0, dacc) are in memory order and the exchange buffer is in INDEX order
+// for its first `placed` entries (a caller's buffer: the ABI speaks the reference's order) — placed = 0 for the context's
+// own buffers, which only ever meet other memory-ordered arrays.
+__global__ __launch_bounds__(WG) void k_delta_out(const float* dacc, float* dst, uint64_t count, uint64_t placed) {
+    uint64_t i = (uint64_t)blockIdx.x * WG + threadIdx.x;
+    uint64_t stride = (uint64_t)gridDim.x * WG;
+    for (; i < count; i += stride) dst[i] = dacc[i < placed ? table_place((uint32_t)i) : i];
+}
+
+__global__ __launch_bounds__(WG) void k_delta_add(float* w, float* w0, const float* delta, float* dacc, uint64_t count, uint64_t placed) {
     uint64_t i = (uint64_t)blockIdx.x * WG + threadIdx.x;
     uint64_t stride = (uint64_t)gridDim.x * WG;
     for (; i < count; i += stride) {
-        float v = w0[i] + delta[i];
-        w[i] = v;
-        w0[i] = v;
-        if (dacc) dacc[i] = 0.0f;
+        const uint64_t p = i < placed ? table_place((uint32_t)i) : i;
+        float v = w0[p] + delta[i];
+        w[p] = v;
+        w0[p] = v;
+        if (dacc) dacc[p] = 0.0f;
     }
 }
 
 // Per-slot mean rule across ranks: pack = [delta | touched] with touched = 1 where this rank moved the slot in the epoch;
 // after the sum all-reduce the slot moves by the mean over the ranks that touched it.
-__global__ __launch_bounds__(WG) void k_delta_pack_touched(const float* dacc, float* pack, uint64_t count) {
+__global__ __launch_bounds__(WG) void k_delta_pack_touched(const float* dacc, float* pack, uint64_t count, uint64_t placed) {
     uint64_t i = (uint64_t)blockIdx.x * WG + threadIdx.x;
     uint64_t stride = (uint64_t)gridDim.x * WG;
     for (; i < count; i += stride) {
-        const float d = dacc[i];
+        const float d = dacc[i < placed ? table_place((uint32_t)i) : i];
         pack[i] = d;
         pack[count + i] = d != 0.0f ? 1.0f : 0.0f;
     }
 }
 
-__global__ __launch_bounds__(WG) void k_delta_add_mean(float* w, float* w0, const float* pack, float* dacc, uint64_t count) {
+__global__ __launch_bounds__(WG) void k_delta_add_mean(float* w, float* w0, const float* pack, float* dacc, uint64_t count, uint64_t placed) {
     uint64_t i = (uint64_t)blockIdx.x * WG + threadIdx.x;
     uint64_t stride = (uint64_t)gridDim.x * WG;
     for (; i < count; i += stride) {
+        const uint64_t p = i < placed ? table_place((uint32_t)i) : i;
         const float n = pack[count + i];
-        float v = w0[i] + (n > 1.0f ? pack[i] / n : pack[i]);
-        w[i] = v;
-        w0[i] = v;
-        dacc[i] = 0.0f;
+        float v = w0[p] + (n > 1.0f ? pack[i] / n : pack[i]);
+        w[p] = v;
+        w0[p] = v;
+        dacc[p] = 0.0f;
     }
 }
 
@@ -1945,6 +1975,7 @@ struct g2048_ctx {
     uint32_t B = 0;
     int n = 0, F = 0;
     uint64_t slots = 0, seed = 0, lane0 = 0;
+    uint64_t placed = 0;                // the leading table slots that live at table_place() (n >= 4: the four- and five-cell tables)
     int auto_reset = 1;
     int cur = 0;                        // which half of `prev` holds the current `state`
     hipStream_t stream = nullptr;
@@ -3016,6 +3047,7 @@ static int create_impl(int device, uint32_t batch, int n_tuple, uint64_t seed, u
     c->n = n_tuple;
     c->F = F;
     c->slots = slots;
+    c->placed = n_tuple >= 4 ? (slots < HEX_BASE ? slots : HEX_BASE) : 0;
     c->seed = seed;
     c->lane0 = lane0;
     int rc = G2048_OK;
@@ -3307,7 +3339,11 @@ int g2048_weights_set(g2048_ctx* c, const float* w, int64_t count) {
     NEED(c, count == (int64_t)c->slots, "weight count does not match the table");
     if (int rc = bind(c)) return rc;
     USE_TABLE(c);
-    return h2d(c, c->w, w, c->slots * 4);
+    if (!c->placed) return h2d(c, c->w, w, c->slots * 4);
+    std::vector<float> tmp(c->placed);              // index order -> memory order (host-side format conversion)
+    for (uint64_t i = 0; i < c->placed; ++i) tmp[table_place((uint32_t)i)] = w[i];
+    if (int rc = h2d(c, c->w, tmp.data(), c->placed * 4)) return rc;
+    return c->slots > c->placed ? h2d(c, c->w + c->placed, w + c->placed, (c->slots - c->placed) * 4) : G2048_OK;
 }
 
 int g2048_weights_get(g2048_ctx* c, float* w, int64_t count) {
@@ -3316,7 +3352,12 @@ int g2048_weights_get(g2048_ctx* c, float* w, int64_t count) {
     NEED(c, count == (int64_t)c->slots, "weight count does not match the table");
     if (int rc = bind(c)) return rc;
     USE_TABLE(c);
-    return d2h(c, w, c->w, c->slots * 4);
+    if (int rc = d2h(c, w, c->w, c->slots * 4)) return rc;
+    if (c->placed) {                                // memory order -> index order
+        std::vector<float> tmp(w, w + c->placed);
+        for (uint64_t i = 0; i < c->placed; ++i) w[i] = tmp[table_place((uint32_t)i)];
+    }
+    return G2048_OK;
 }
 
 int g2048_weights_init(g2048_ctx* c, uint64_t seed, float scale) {
@@ -3324,7 +3365,7 @@ int g2048_weights_init(g2048_ctx* c, uint64_t seed, float scale) {
     NEED_TABLE(c);
     if (int rc = bind(c)) return rc;
     USE_TABLE(c);
-    k_weights_init<<<2048, WG, 0, c->stream>>>(c->w, c->slots, seed, scale);
+    k_weights_init<<<2048, WG, 0, c->stream>>>(c->w, c->slots, c->placed, seed, scale);
     return launched(c, "k_weights_init");
 }
 
@@ -3652,7 +3693,10 @@ int g2048_delta_extract(g2048_ctx* c, void* dst) {
     if (!c->tracking) return fail(c, G2048_ERR_STATE, "g2048_delta_begin was not called");
     if (int rc = bind(c)) return rc;
     USE_TABLE(c);
-    if (dst) HIP_TRY(c, hipMemcpyAsync(dst, c->delta, c->slots * 4, hipMemcpyDeviceToDevice, c->stream));
+    if (dst) {
+        k_delta_out<<<2048, WG, 0, c->stream>>>(c->delta, (float*)dst, c->slots, c->placed);
+        if (int rc = launched(c, "k_delta_out")) return rc;
+    }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return G2048_OK;
 }
@@ -3663,7 +3707,7 @@ int g2048_delta_apply(g2048_ctx* c, const void* src) {
     if (!c->tracking) return fail(c, G2048_ERR_STATE, "g2048_delta_begin was not called");
     if (int rc = bind(c)) return rc;
     USE_TABLE(c);
-    k_delta_add<<<2048, WG, 0, c->stream>>>(c->w, c->w0, src ? (const float*)src : c->delta, c->delta, c->slots);
+    k_delta_add<<<2048, WG, 0, c->stream>>>(c->w, c->w0, src ? (const float*)src : c->delta, c->delta, c->slots, src ? c->placed : 0);
     if (int rc = launched(c, "k_delta_add")) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return G2048_OK;
@@ -3675,7 +3719,7 @@ int g2048_delta_apply_mean(g2048_ctx* c, const void* pack) {
     if (!c->tracking) return fail(c, G2048_ERR_STATE, "g2048_delta_begin was not called");
     if (int rc = bind(c)) return rc;
     USE_TABLE(c);
-    k_delta_add_mean<<<2048, WG, 0, c->stream>>>(c->w, c->w0, (const float*)pack, c->delta, c->slots);
+    k_delta_add_mean<<<2048, WG, 0, c->stream>>>(c->w, c->w0, (const float*)pack, c->delta, c->slots, c->placed);
     if (int rc = launched(c, "k_delta_add_mean")) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return G2048_OK;
@@ -3687,7 +3731,7 @@ int g2048_delta_pack_touched(g2048_ctx* c, void* pack) {
     if (!c->tracking) return fail(c, G2048_ERR_STATE, "g2048_delta_begin was not called");
     if (int rc = bind(c)) return rc;
     USE_TABLE(c);
-    k_delta_pack_touched<<<2048, WG, 0, c->stream>>>(c->delta, (float*)pack, c->slots);
+    k_delta_pack_touched<<<2048, WG, 0, c->stream>>>(c->delta, (float*)pack, c->slots, c->placed);
     if (int rc = launched(c, "k_delta_pack_touched")) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return G2048_OK;
@@ -3798,15 +3842,15 @@ int g2048_allreduce_deltas(g2048_ctx* c) {
     const size_t n = c->slots;
     if (c->update_rule == 1) {
         if (int rc = ensure_pack(c, 2 * n)) return rc;
-        k_delta_pack_touched<<<2048, WG, 0, c->stream>>>(c->delta, c->pack, n);
+        k_delta_pack_touched<<<2048, WG, 0, c->stream>>>(c->delta, c->pack, n, 0);
         ncclResult_t e = r->AllReduce(c->pack, c->pack, 2 * n, ncclFloat32, ncclSum, (ncclComm_t)c->comm, c->stream);
         if (e != ncclSuccess) return rccl_fail(c, "ncclAllReduce", e);
-        k_delta_add_mean<<<2048, WG, 0, c->stream>>>(c->w, c->w0, c->pack, c->delta, n);
+        k_delta_add_mean<<<2048, WG, 0, c->stream>>>(c->w, c->w0, c->pack, c->delta, n, 0);
     } else {
         if (int rc = ensure_pack(c, n)) return rc;
         ncclResult_t e = r->AllReduce(c->delta, c->pack, n, ncclFloat32, ncclSum, (ncclComm_t)c->comm, c->stream);
         if (e != ncclSuccess) return rccl_fail(c, "ncclAllReduce", e);
-        k_delta_add<<<2048, WG, 0, c->stream>>>(c->w, c->w0, c->pack, c->delta, n);
+        k_delta_add<<<2048, WG, 0, c->stream>>>(c->w, c->w0, c->pack, c->delta, n, 0);
     }
     return launched(c, "g2048_allreduce_deltas");
 }
