@@ -205,6 +205,59 @@ G2048_HD void hex_slots(const Packed& p, uint32_t out[12]) {
         }
 }
 
+// ---- where an entry of a six-cell (base-14) table lives in memory: the same idea as table_place.  Index k = sum d_p 14^p
+// goes to 64 * (sum (d_p >> 1) 7^p) + sum (d_p & 1) 2^p — a bijection of [0, 14^6) (7^6 * 64 = 14^6): the six low digit
+// bits select the entry inside a 256-byte block and the block is chosen by the digits' upper parts, of which small tiles
+// have few (tiles <= 32: 3^6 = 729 blocks per table instead of 6^5 = 7 776 lines).
+G2048_HD uint32_t hex_place(uint32_t k) {
+    uint32_t hi = 0, lo = 0, m7 = 1;
+    for (uint32_t p = 0; p < 6u; ++p) {
+        const uint32_t d = k % 14u;
+        k /= 14u;
+        hi += (d >> 1) * m7;
+        lo |= (d & 1u) << p;
+        m7 *= 7u;
+    }
+    return 64u * hi + lo;
+}
+
+// a slot of an n >= 4 table -> its place in memory
+G2048_HD uint32_t table_place_any(uint32_t slot) {
+    if (slot < HEX_BASE) return table_place(slot);
+    const uint32_t t = (slot - HEX_BASE) / HEX_SIZE, k = slot - HEX_BASE - t * HEX_SIZE;
+    return HEX_BASE + t * HEX_SIZE + hex_place(k);
+}
+
+// hex_slots with every entry already at its place: table_place_any(hex_slots()[j]) without the digit extraction
+G2048_HD void hex_slots_placed(const Packed& p, uint32_t out[12]) {
+    uint32_t h[4][4], l[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            uint32_t v = G2048_CELL(p, r, c);
+            v = v > 13u ? 13u : v;
+            h[r][c] = v >> 1;
+            l[r][c] = v & 1u;
+        }
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const uint32_t a = 49u * h[r][c] + 7u * h[r + 1][c] + h[r + 2][c], la = l[r][c] << 2 | l[r + 1][c] << 1 | l[r + 2][c];
+            const uint32_t b = 49u * h[r][c + 1] + 7u * h[r + 1][c + 1] + h[r + 2][c + 1], lb = l[r][c + 1] << 2 | l[r + 1][c + 1] << 1 | l[r + 2][c + 1];
+            out[3 * r + c] = HEX_BASE + (uint32_t)(3 * r + c) * HEX_SIZE + 64u * (343u * a + b) + (la << 3 | lb);
+        }
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const uint32_t a = 49u * h[r][c] + 7u * h[r][c + 1] + h[r][c + 2], la = l[r][c] << 2 | l[r][c + 1] << 1 | l[r][c + 2];
+            const uint32_t b = 49u * h[r + 1][c] + 7u * h[r + 1][c + 1] + h[r + 1][c + 2], lb = l[r + 1][c] << 2 | l[r + 1][c + 1] << 1 | l[r + 1][c + 2];
+            out[6 + 2 * r + c] = HEX_BASE + (uint32_t)(6 + 2 * r + c) * HEX_SIZE + 64u * (343u * a + b) + (la << 3 | lb);
+        }
+}
+
 template <>
 G2048_HD void feature_slots<4>(const Packed& p, uint32_t out[17]) { quad_slots(p, out); }
 
@@ -219,6 +272,22 @@ G2048_HD void feature_slots<6>(const Packed& p, uint32_t out[33]) {
     quad_slots(p, out);
     cross_slots(p, out + 17);
     hex_slots(p, out + 21);
+}
+
+// feature_slots at their places in memory: what the kernels that read or write the table use (n = 2, 3: index order)
+template <int N>
+G2048_HD void memory_slots(const Packed& p, uint32_t* out) {
+    feature_slots<N>(p, out);
+    if (N >= 4) {
+        for (int f = 0; f < (N == 4 ? 17 : 21); ++f) out[f] = table_place(out[f]);
+    }
+}
+template <>
+G2048_HD void memory_slots<6>(const Packed& p, uint32_t* out) {
+    quad_slots(p, out);
+    cross_slots(p, out + 17);
+    for (int f = 0; f < 21; ++f) out[f] = table_place(out[f]);
+    hex_slots_placed(p, out + 21);
 }
 
 // first slot of feature i (host-side layout queries)

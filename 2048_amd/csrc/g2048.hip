@@ -325,28 +325,21 @@ __global__ __launch_bounds__(WG) void k_features(const uint4* boards, uint32_t B
 // One table entry.  (Forcing the scalar-base + 32-bit-vector-offset form of global_load — an opaque 32-bit byte offset,
 // so that a pending gather holds one address register instead of a 64-bit pair — was measured: same register count after
 // allocation, k_td_play 0.200 -> 0.210 ms.  Plain indexing it is.)
-// feature f's slot -> its place in memory (table_place: n >= 4, features 0..20; the f_6 tables and n = 2, 3 are in index order)
-template <int N>
-__device__ __forceinline__ uint32_t place(uint32_t slot, int f) {
-    if constexpr (N < 4) return slot;
-    return f < 21 ? table_place(slot) : slot;
-}
+// (the slots handed to ld_w are memory slots: memory_slots<N>, features.hpp)
 #ifdef G2048_EXP_NOGATHER        // (experiment: what k_td_play costs without its table reads)
-template <int N>
-__device__ __forceinline__ float ld_w(const float* __restrict__ w, uint32_t slot, int f) { return __uint_as_float(0x30000000u | (slot & 0xFFFFu)); }
+__device__ __forceinline__ float ld_w(const float* __restrict__ w, uint32_t slot) { return __uint_as_float(0x30000000u | (slot & 0xFFFFu)); }
 #else
-template <int N>
-__device__ __forceinline__ float ld_w(const float* __restrict__ w, uint32_t slot, int f) { return w[place<N>(slot, f)]; }
+__device__ __forceinline__ float ld_w(const float* __restrict__ w, uint32_t slot) { return w[slot]; }
 #endif
 
 template <int N>
 __device__ __forceinline__ float value_of(const float* __restrict__ w, const Board& b) {
     constexpr int F = Shape<N>::F;
     uint32_t s[F];
-    feature_slots<N>(pack_board(b), s);
+    memory_slots<N>(pack_board(b), s);
     float x[F];
 #pragma unroll
-    for (int f = 0; f < F; ++f) x[f] = ld_w<N>(w, s[f], f);
+    for (int f = 0; f < F; ++f) x[f] = ld_w(w, s[f]);
     float v = 0.0f;
 #pragma unroll
     for (int f = 0; f < F; ++f) v += x[f];
@@ -388,17 +381,17 @@ __device__ __forceinline__ Choice choose(const float* __restrict__ w, const Move
     int first_valid = -1;
     if constexpr (F <= G2048_BATCH4_MAXF) {
         uint32_t s0[F], s1[F], s2[F], s3[F];
-        feature_slots<N>(pack_board(mv.m0.after), s0);
-        feature_slots<N>(pack_board(mv.m1.after), s1);
-        feature_slots<N>(pack_board(mv.m2.after), s2);
-        feature_slots<N>(pack_board(mv.m3.after), s3);
+        memory_slots<N>(pack_board(mv.m0.after), s0);
+        memory_slots<N>(pack_board(mv.m1.after), s1);
+        memory_slots<N>(pack_board(mv.m2.after), s2);
+        memory_slots<N>(pack_board(mv.m3.after), s3);
         float x0[F], x1[F], x2[F], x3[F];
 #pragma unroll
         for (int f = 0; f < F; ++f) {
-            x0[f] = ld_w<N>(w, mv.m0.changed ? s0[f] : 0u, f);
-            x1[f] = ld_w<N>(w, mv.m1.changed ? s1[f] : 0u, f);
-            x2[f] = ld_w<N>(w, mv.m2.changed ? s2[f] : 0u, f);
-            x3[f] = ld_w<N>(w, mv.m3.changed ? s3[f] : 0u, f);
+            x0[f] = ld_w(w, mv.m0.changed ? s0[f] : 0u);
+            x1[f] = ld_w(w, mv.m1.changed ? s1[f] : 0u);
+            x2[f] = ld_w(w, mv.m2.changed ? s2[f] : 0u);
+            x3[f] = ld_w(w, mv.m3.changed ? s3[f] : 0u);
         }
         float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f, v3 = 0.0f;      // each a left-to-right sum, as QAgent.evaluate
 #pragma unroll
@@ -427,12 +420,12 @@ __device__ __forceinline__ Choice choose(const float* __restrict__ w, const Move
 #define G2048_TRY_PAIR(DA, MA, DB, MB)                                               \
     {                                                                                \
         uint32_t sa[F], sb[F];                                                       \
-        feature_slots<N>(pack_board((MA).after), sa);                                \
-        feature_slots<N>(pack_board((MB).after), sb);                                \
+        memory_slots<N>(pack_board((MA).after), sa);                                \
+        memory_slots<N>(pack_board((MB).after), sb);                                \
         float xa[F], xb[F];                                                          \
         _Pragma("unroll") for (int f = 0; f < F; ++f) {                              \
-            xa[f] = ld_w<N>(w, (MA).changed ? sa[f] : 0u, f);                              \
-            xb[f] = ld_w<N>(w, (MB).changed ? sb[f] : 0u, f);                              \
+            xa[f] = ld_w(w, (MA).changed ? sa[f] : 0u);                              \
+            xb[f] = ld_w(w, (MB).changed ? sb[f] : 0u);                              \
         }                                                                            \
         float va = 0.0f, vb = 0.0f;                                                  \
         _Pragma("unroll") for (int f = 0; f < F; ++f) {                              \
@@ -530,10 +523,11 @@ __device__ __forceinline__ Choice choose_hot(const float* __restrict__ w, const 
 #define G2048_HOT_DIR(M, X)                                                                 \
     float X[F];                                                                             \
     {                                                                                       \
-        uint32_t s[F];                                                                      \
+        uint32_t s[F], ms[F];           /* index order for the hot test, memory order for the rest */ \
         feature_slots<N>(pack_board((M).after), s);                                         \
+        memory_slots<N>(pack_board((M).after), ms);                                         \
         _Pragma("unroll") for (int f = 0; f < 17; ++f) X[f] = ld_quad(w, hot, (uint32_t)f, s[f], (M).changed); \
-        _Pragma("unroll") for (int f = 17; f < F; ++f) X[f] = ld_w<N>(w, (M).changed ? s[f] : 0u, f);                \
+        _Pragma("unroll") for (int f = 17; f < F; ++f) X[f] = ld_w(w, (M).changed ? ms[f] : 0u);               \
     }
     if constexpr (F <= G2048_BATCH4_MAXF) {
         G2048_HOT_DIR(mv.m0, x0)
@@ -617,9 +611,7 @@ template <int N>
 __device__ __forceinline__ void scatter_image(float* w, float* dacc, const Packed& state, uint32_t g, float dw) {
     constexpr int F = Shape<N>::F;
     uint32_t s[F];
-    feature_slots<N>(d4_image(state, g), s);
-#pragma unroll
-    for (int f = 0; f < F; ++f) s[f] = place<N>(s[f], f);
+    memory_slots<N>(d4_image(state, g), s);
 #pragma unroll
     for (int f = 0; f < F; ++f) __hip_atomic_fetch_add(&w[s[f]], dw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (dacc) {
@@ -1158,6 +1150,24 @@ G2048_HD uint32_t permute_digits(uint32_t k, uint32_t perm, uint32_t digits, uin
     return out;
 }
 
+// permute_digits for a base-14 index, delivered at its place in memory (hex_place of the result, without a second digit extraction)
+G2048_HD uint32_t permute_hex_placed(uint32_t k, uint32_t perm) {
+    uint32_t d[6], hi = 0, lo = 0, m7 = 1;
+    for (uint32_t p = 0; p < 6u; ++p) {
+        d[p] = k % 14u;
+        k /= 14u;
+    }
+    for (uint32_t p = 0; p < 6u; ++p) {
+        const uint32_t src = (perm >> (3u * p)) & 7u;
+        uint32_t v = d[0];
+        v = src == 1u ? d[1] : v; v = src == 2u ? d[2] : v; v = src == 3u ? d[3] : v; v = src == 4u ? d[4] : v; v = src == 5u ? d[5] : v;
+        hi += (v >> 1) * m7;
+        lo |= (v & 1u) << p;
+        m7 *= 7u;
+    }
+    return 64u * hi + lo;
+}
+
 #ifndef G2048_OWN_U
 #define G2048_OWN_U 4       // records per thread in flight in the owner kernel's scan (n >= 4)
 #endif
@@ -1450,8 +1460,7 @@ __device__ __forceinline__ void mirror_stats(const StatMirror& m) {
 // table_i[perm_i(k)] += v for every member i of the orbit; `dacc` (may be null) mirrors the add (g2048_delta_begin)
 __device__ __forceinline__ void add_to_members(float* w, float* dacc, const OrbitInfo& oi, uint32_t k, float v) {
     for (uint32_t m = 0; m < oi.nmem; ++m) {
-        uint32_t slot = oi.off[m] + permute_digits(k, oi.perm[m], oi.digits, oi.radix);
-        if (slot < HEX_BASE) slot = table_place(slot);
+        const uint32_t slot = oi.radix == 16u ? table_place(oi.off[m] + permute_digits(k, oi.perm[m], oi.digits, 16u)) : oi.off[m] + permute_hex_placed(k, oi.perm[m]);
         w[slot] += v;
         if (dacc) dacc[slot] += v;
     }
@@ -1907,7 +1916,7 @@ __global__ __launch_bounds__(WG) void k_weights_init(float* w, uint64_t count, u
     for (; i < count; i += stride) {
         uint64_t x = seed + i;
         uint64_t z = splitmix64(x);
-        w[i < placed ? table_place((uint32_t)i) : i] = (float)(z >> 40) * (1.0f / 16777216.0f) * scale;
+        w[i < placed ? table_place_any((uint32_t)i) : i] = (float)(z >> 40) * (1.0f / 16777216.0f) * scale;
     }
 }
 
@@ -1924,14 +1933,21 @@ __global__ __launch_bounds__(WG) void k_delta_sub(const float* w, const float* w
 __global__ __launch_bounds__(WG) void k_delta_out(const float* dacc, float* dst, uint64_t count, uint64_t placed) {
     uint64_t i = (uint64_t)blockIdx.x * WG + threadIdx.x;
     uint64_t stride = (uint64_t)gridDim.x * WG;
-    for (; i < count; i += stride) dst[i] = dacc[i < placed ? table_place((uint32_t)i) : i];
+    for (; i < count; i += stride) dst[i] = dacc[i < placed ? table_place_any((uint32_t)i) : i];
+}
+
+// the whole table between index order (`flat`, a staging buffer) and memory order (g2048_weights_get / _set)
+__global__ __launch_bounds__(WG) void k_table_in(float* w, const float* flat, uint64_t count) {
+    uint64_t i = (uint64_t)blockIdx.x * WG + threadIdx.x;
+    uint64_t stride = (uint64_t)gridDim.x * WG;
+    for (; i < count; i += stride) w[table_place_any((uint32_t)i)] = flat[i];
 }
 
 __global__ __launch_bounds__(WG) void k_delta_add(float* w, float* w0, const float* delta, float* dacc, uint64_t count, uint64_t placed) {
     uint64_t i = (uint64_t)blockIdx.x * WG + threadIdx.x;
     uint64_t stride = (uint64_t)gridDim.x * WG;
     for (; i < count; i += stride) {
-        const uint64_t p = i < placed ? table_place((uint32_t)i) : i;
+        const uint64_t p = i < placed ? table_place_any((uint32_t)i) : i;
         float v = w0[p] + delta[i];
         w[p] = v;
         w0[p] = v;
@@ -1945,7 +1961,7 @@ __global__ __launch_bounds__(WG) void k_delta_pack_touched(const float* dacc, fl
     uint64_t i = (uint64_t)blockIdx.x * WG + threadIdx.x;
     uint64_t stride = (uint64_t)gridDim.x * WG;
     for (; i < count; i += stride) {
-        const float d = dacc[i < placed ? table_place((uint32_t)i) : i];
+        const float d = dacc[i < placed ? table_place_any((uint32_t)i) : i];
         pack[i] = d;
         pack[count + i] = d != 0.0f ? 1.0f : 0.0f;
     }
@@ -1955,7 +1971,7 @@ __global__ __launch_bounds__(WG) void k_delta_add_mean(float* w, float* w0, cons
     uint64_t i = (uint64_t)blockIdx.x * WG + threadIdx.x;
     uint64_t stride = (uint64_t)gridDim.x * WG;
     for (; i < count; i += stride) {
-        const uint64_t p = i < placed ? table_place((uint32_t)i) : i;
+        const uint64_t p = i < placed ? table_place_any((uint32_t)i) : i;
         const float n = pack[count + i];
         float v = w0[p] + (n > 1.0f ? pack[i] / n : pack[i]);
         w[p] = v;
@@ -1975,7 +1991,7 @@ struct g2048_ctx {
     uint32_t B = 0;
     int n = 0, F = 0;
     uint64_t slots = 0, seed = 0, lane0 = 0;
-    uint64_t placed = 0;                // the leading table slots that live at table_place() (n >= 4: the four- and five-cell tables)
+    uint64_t placed = 0;                // the leading table slots that live at table_place_any(): all of them for n >= 4, none for n = 2, 3
     int auto_reset = 1;
     int cur = 0;                        // which half of `prev` holds the current `state`
     hipStream_t stream = nullptr;
@@ -3047,7 +3063,7 @@ static int create_impl(int device, uint32_t batch, int n_tuple, uint64_t seed, u
     c->n = n_tuple;
     c->F = F;
     c->slots = slots;
-    c->placed = n_tuple >= 4 ? (slots < HEX_BASE ? slots : HEX_BASE) : 0;
+    c->placed = n_tuple >= 4 ? slots : 0;
     c->seed = seed;
     c->lane0 = lane0;
     int rc = G2048_OK;
@@ -3340,10 +3356,17 @@ int g2048_weights_set(g2048_ctx* c, const float* w, int64_t count) {
     if (int rc = bind(c)) return rc;
     USE_TABLE(c);
     if (!c->placed) return h2d(c, c->w, w, c->slots * 4);
-    std::vector<float> tmp(c->placed);              // index order -> memory order (host-side format conversion)
-    for (uint64_t i = 0; i < c->placed; ++i) tmp[table_place((uint32_t)i)] = w[i];
-    if (int rc = h2d(c, c->w, tmp.data(), c->placed * 4)) return rc;
-    return c->slots > c->placed ? h2d(c, c->w + c->placed, w + c->placed, (c->slots - c->placed) * 4) : G2048_OK;
+    float* flat = nullptr;                          // index order -> memory order through a staging buffer
+    hipError_t e = hipMalloc(&flat, c->slots * 4);
+    if (e != hipSuccess) return fail(c, G2048_ERR_NOMEM, "hipMalloc(table staging)", e);
+    int rc = h2d(c, flat, w, c->slots * 4);
+    if (!rc) {
+        k_table_in<<<2048, WG, 0, c->stream>>>(c->w, flat, c->slots);
+        rc = launched(c, "k_table_in");
+    }
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(flat);
+    return rc;
 }
 
 int g2048_weights_get(g2048_ctx* c, float* w, int64_t count) {
@@ -3352,12 +3375,16 @@ int g2048_weights_get(g2048_ctx* c, float* w, int64_t count) {
     NEED(c, count == (int64_t)c->slots, "weight count does not match the table");
     if (int rc = bind(c)) return rc;
     USE_TABLE(c);
-    if (int rc = d2h(c, w, c->w, c->slots * 4)) return rc;
-    if (c->placed) {                                // memory order -> index order
-        std::vector<float> tmp(w, w + c->placed);
-        for (uint64_t i = 0; i < c->placed; ++i) w[i] = tmp[table_place((uint32_t)i)];
-    }
-    return G2048_OK;
+    if (!c->placed) return d2h(c, w, c->w, c->slots * 4);
+    float* flat = nullptr;                          // memory order -> index order through a staging buffer
+    hipError_t e = hipMalloc(&flat, c->slots * 4);
+    if (e != hipSuccess) return fail(c, G2048_ERR_NOMEM, "hipMalloc(table staging)", e);
+    k_delta_out<<<2048, WG, 0, c->stream>>>(c->w, flat, c->slots, c->placed);
+    int rc = launched(c, "k_delta_out");
+    if (!rc) rc = d2h(c, w, flat, c->slots * 4);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(flat);
+    return rc;
 }
 
 int g2048_weights_init(g2048_ctx* c, uint64_t seed, float scale) {

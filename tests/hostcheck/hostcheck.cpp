@@ -104,4 +104,28 @@ int hc_image_slots(int n, const uint8_t* boards, int64_t count, int32_t* out) {
     }
     return 0;
 }
+// where table slots live in memory (table_place_any) and memory_slots<n> of boards: out[count][F]
+void hc_table_place(const uint32_t* slots, int64_t count, uint32_t* out) {
+    for (int64_t i = 0; i < count; ++i) out[i] = table_place_any(slots[i]);
+}
+void hc_hex_place(uint32_t first, int64_t count, uint32_t* out) {
+    for (int64_t i = 0; i < count; ++i) out[i] = hex_place(first + (uint32_t)i);
+}
+int hc_memory_slots(int n, const uint8_t* boards, int64_t count, int32_t* out) {
+    for (int64_t i = 0; i < count; ++i) {
+        Packed p = pack_board(load(boards + 16 * i));
+        uint32_t s[52];
+        int F;
+        switch (n) {
+            case 2: memory_slots<2>(p, s); F = 24; break;
+            case 3: memory_slots<3>(p, s); F = 52; break;
+            case 4: memory_slots<4>(p, s); F = 17; break;
+            case 5: memory_slots<5>(p, s); F = 21; break;
+            case 6: memory_slots<6>(p, s); F = 33; break;
+            default: return -1;
+        }
+        for (int f = 0; f < F; ++f) out[i * F + f] = (int32_t)s[f];
+    }
+    return 0;
+}
 }

@@ -180,3 +180,51 @@ def test_rng_stream_and_new_games(hc):
         r10, k = rng_spec.spawn_draw_np(rng_spec.next_u64_np(st), rb.empty_count(want))
         want, _, _ = rb.spawn_injected(want, r10, k)
     assert np.array_equal(boards.reshape(-1, 4, 4), want)
+
+
+def test_table_places_are_bijections_and_memory_slots_agree(hc, golden):
+    """The table is stored in another order than it is indexed (features.hpp: table_place / hex_place).  Both maps must
+    be bijections of their block, and memory_slots<n> — what the kernels address the table with — must be the place of
+    feature_slots<n>, for every n (n = 2, 3: unchanged)."""
+    from oracle import ref_scalar as rs
+    for block in (0, 5, 16, 17, 40, 80):                     # 65 536-entry blocks of the four- and five-cell tables
+        slots = (np.arange(65536, dtype=np.uint32) + np.uint32(block * 65536))
+        out = np.zeros_like(slots)
+        hc.hc_table_place(ptr(slots), ctypes.c_int64(len(slots)), ptr(out))
+        assert np.array_equal(np.sort(out), slots)
+        assert not np.array_equal(out, slots)
+    hexn = 14 ** 6
+    out = np.zeros(hexn, np.uint32)
+    hc.hc_hex_place(ctypes.c_uint32(0), ctypes.c_int64(hexn), ptr(out))
+    assert np.array_equal(np.sort(out), np.arange(hexn, dtype=np.uint32))
+    k = np.arange(hexn, dtype=np.int64)                       # the stated formula: 64 * sum (d_p >> 1) 7^p + sum (d_p & 1) 2^p
+    want = np.zeros(hexn, np.int64)
+    for p in range(6):
+        d = (k // 14 ** p) % 14
+        want += 64 * (d >> 1) * 7 ** p + ((d & 1) << p)
+    assert np.array_equal(out.astype(np.int64), want)
+    g = golden('features.npz')
+    boards = np.ascontiguousarray(g['boards'].reshape(-1, 16))
+    extra = np.random.RandomState(3).randint(0, 16, size=(4096, 16)).astype(np.uint8)     # tiles 14, 15 too (the base-14 clamp)
+    boards = np.ascontiguousarray(np.concatenate([boards, extra]))
+    for n in (2, 3, 4, 5, 6):
+        offs, total = rs.feature_offsets(n)
+        F = len(offs)
+        logical = np.zeros((len(boards), 8, F), np.int32)
+        assert hc.hc_image_slots(n, ptr(boards), ctypes.c_int64(len(boards)), ptr(logical)) == 0
+        logical = np.ascontiguousarray(logical[:, 0, :]).astype(np.uint32)
+        mem = np.zeros((len(boards), F), np.int32)
+        assert hc.hc_memory_slots(n, ptr(boards), ctypes.c_int64(len(boards)), ptr(mem)) == 0
+        if n < 4:
+            assert np.array_equal(mem.astype(np.uint32), logical)
+            continue
+        placed = np.zeros(logical.size, np.uint32)
+        flat = np.ascontiguousarray(logical.reshape(-1))
+        hc.hc_table_place(ptr(flat), ctypes.c_int64(flat.size), ptr(placed))
+        assert np.array_equal(mem.astype(np.uint32).reshape(-1), placed)
+        assert placed.max() < total
+        # a feature's entries stay inside its own table
+        lo = np.asarray(offs, np.int64)[None, :]
+        hi = np.append(np.asarray(offs, np.int64)[1:], total)[None, :]
+        m = mem.astype(np.int64)
+        assert (m >= lo).all() and (m < hi).all()
