@@ -193,7 +193,11 @@ int g2048_stats_reset(g2048_ctx* ctx);
  *   host-driven:  delta_extract -> any all-reduce of the caller (torch.distributed) -> delta_apply; these three synchronise
  *                 the context's stream.  dst/src are DEVICE pointers to fp32[table_slots] owned by the caller, or NULL for
  *                 the context's own accumulator (g2048_delta_device_ptr).  Mean rule: delta_pack_touched(pack fp32[2 * slots])
- *                 -> all-reduce(pack) -> delta_apply_mean(pack). */
+ *                 -> all-reduce(pack) -> delta_apply_mean(pack).
+ * Order of entries: every buffer the CALLER owns (g2048_weights_get / _set, dst / src / pack above) is in the reference's
+ * index order (g2048_feature_layout).  The table and the accumulator themselves are stored in another order (n >= 4: see
+ * table_place / hex_place in csrc/features.hpp): the raw pointers g2048_weights_device_ptr and
+ * g2048_delta_device_ptr are good for element-wise work between replicas (broadcast, all-reduce) only. */
 #define G2048_COMM_ID_BYTES 128
 int g2048_comm_unique_id(uint8_t* id /* [G2048_COMM_ID_BYTES] */);
 int g2048_comm_init(g2048_ctx* ctx, int rank, int nranks, const uint8_t* id /* [G2048_COMM_ID_BYTES] */);
