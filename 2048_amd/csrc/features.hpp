@@ -221,6 +221,17 @@ G2048_HD uint32_t hex_place(uint32_t k) {
     return 64u * hi + lo;
 }
 
+// the inverse of hex_place
+G2048_HD uint32_t hex_unplace(uint32_t j) {
+    uint32_t hi = j >> 6, k = 0, m14 = 1;
+    for (uint32_t p = 0; p < 6u; ++p) {
+        k += (2u * (hi % 7u) + ((j >> p) & 1u)) * m14;
+        hi /= 7u;
+        m14 *= 14u;
+    }
+    return k;
+}
+
 // a slot of an n >= 4 table -> its place in memory
 G2048_HD uint32_t table_place_any(uint32_t slot) {
     if (slot < HEX_BASE) return table_place(slot);

@@ -1667,13 +1667,14 @@ struct HexBufs {
 constexpr int HEX_PAIRS = 16;
 template <int N>
 __device__ __forceinline__ void hex_record_slots(const Packed& p, uint32_t (&out)[HEX_PAIRS]) {
-    constexpr int F = Shape<N>::F;
+    // The two orbit tables are indexed in hex_place order, like the member tables in memory: boards with small tiles then
+    // fall into a few dozen of the 920 chunks instead of a few hundred, which is what the count / scatter / apply passes pay for.
 #pragma unroll
     for (uint32_t g = 0; g < 8; ++g) {
-        uint32_t s[F];
-        feature_slots<N>(d4_image(p, g), s);
-        out[g] = s[21] - feature_offset(N, 21);
-        out[8 + g] = HEX_SIZE + (s[22] - feature_offset(N, 22));
+        uint32_t s[12];
+        hex_slots_placed(d4_image(p, g), s);            // (only the two representatives' entries survive dead-code elimination)
+        out[g] = s[0] - HEX_BASE;
+        out[8 + g] = HEX_SIZE + (s[1] - HEX_BASE - HEX_SIZE);
     }
 }
 
@@ -1834,9 +1835,9 @@ __global__ __launch_bounds__(WG) void k_hex_apply(float* w, float* dacc, float* 
     }
     Dh[K] = 0.0f;
     if (K < HEX_SIZE)
-        add_to_members(w, dacc, oa, K, v);
+        add_to_members(w, dacc, oa, hex_unplace(K), v);
     else
-        add_to_members(w, dacc, ob, K - HEX_SIZE, v);
+        add_to_members(w, dacc, ob, hex_unplace(K - HEX_SIZE), v);
 }
 
 // ------------------------------------------------------------------------------------------------ lane order (LaneSort)
