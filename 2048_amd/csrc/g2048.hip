@@ -51,14 +51,27 @@ __device__ __forceinline__ Board ld_board(const uint4* p, size_t i) {
     b.r[0] = v.x; b.r[1] = v.y; b.r[2] = v.z; b.r[3] = v.w;
     return b;
 }
-__device__ __forceinline__ void st_board(uint4* p, size_t i, const Board& b) { p[i] = make_uint4(b.r[0], b.r[1], b.r[2], b.r[3]); }
+#ifdef G2048_EXP_NT_STORES      // (experiment: the lane state streamed past the caches)
+#define G2048_ST(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#else
+#define G2048_ST(ptr, val) (*(ptr) = (val))
+#endif
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void st_board(uint4* p, size_t i, const Board& b) {
+    u32x4_t v = {b.r[0], b.r[1], b.r[2], b.r[3]};
+    G2048_ST(reinterpret_cast<u32x4_t*>(p) + i, v);
+}
 __device__ __forceinline__ Rng ld_rng(const ulonglong2* p, size_t i) {
     ulonglong2 v = p[i];
     Rng g;
     g.s0 = v.x; g.s1 = v.y;
     return g;
 }
-__device__ __forceinline__ void st_rng(ulonglong2* p, size_t i, const Rng& g) { p[i] = make_ulonglong2(g.s0, g.s1); }
+__device__ __forceinline__ void st_rng(ulonglong2* p, size_t i, const Rng& g) {
+    u64x2_t v = {g.s0, g.s1};
+    G2048_ST(reinterpret_cast<u64x2_t*>(p) + i, v);
+}
 
 // `state` records are kept in packed form (features.hpp): x = R0|R1<<16, y = R2|R3<<16, z = C0|C1<<16, w = C2|C3<<16
 __device__ __forceinline__ Packed ld_packed(const uint4* p, size_t i) {
@@ -69,7 +82,8 @@ __device__ __forceinline__ Packed ld_packed(const uint4* p, size_t i) {
     return q;
 }
 __device__ __forceinline__ void st_packed(uint4* p, size_t i, const Packed& q) {
-    p[i] = make_uint4(q.R[0] | (q.R[1] << 16), q.R[2] | (q.R[3] << 16), q.C[0] | (q.C[1] << 16), q.C[2] | (q.C[3] << 16));
+    u32x4_t v = {q.R[0] | (q.R[1] << 16), q.R[2] | (q.R[3] << 16), q.C[0] | (q.C[1] << 16), q.C[2] | (q.C[3] << 16)};
+    G2048_ST(reinterpret_cast<u32x4_t*>(p) + i, v);
 }
 
 struct Stats {   // device mirror of g2048_stats (all u64)
@@ -1006,9 +1020,9 @@ __global__ __launch_bounds__(TPB, G2048_PLAY_MIN_WAVES) void k_td_play(LaneSet i
             PHASE_STAMP(6);     // (finished games: statistics, new game)
             st_board(out.boards, i, b);
             st_rng(out.rng, i, g);
-            out.scores[i] = score;
-            out.label[i] = old_label;
-            out.flags[i] = fl;
+            G2048_ST(out.scores + i, score);
+            G2048_ST(out.label + i, old_label);
+            G2048_ST(out.flags + i, fl);
         }
         // a record whose dw is not finite (a table poisoned with inf / NaN) is dropped and counted: the fixed-point sums
         // of the LDS-owner update have no encoding for it
@@ -1017,7 +1031,7 @@ __global__ __launch_bounds__(TPB, G2048_PLAY_MIN_WAVES) void k_td_play(LaneSet i
             dw1 = 0.0f;
         }
         recs.dw1[src] = dw1;
-        out.last_move[i] = (uint16_t)lm;
+        G2048_ST(out.last_move + i, (uint16_t)lm);
         dw_big = fmaxf(dw_big, fabsf(dw1));
         PHASE_STAMP(7);         // (stores issued)
     }
