@@ -1266,28 +1266,42 @@ __device__ __forceinline__ void own_accum(const Packed& p, float dw, bool valid,
 // the same accumulation from precomputed orbit indices (k_td_play's OrbitIdx records); idx are relative to the orbit table
 template <int NI, bool FB, bool FIXED>
 __device__ __forceinline__ void own_accum_idx(const uint32_t (&idx)[NI], float dw, bool valid, float* acc, const Slice& sl, uint32_t lo_rel,
-                                              uint32_t& nhit_wave, float* D, float* Dc, uint32_t* fb_hits, double scale, uint32_t cbits) {
-    unsigned long long fixed = 0;
-    if (FIXED) fixed = packed_add(dw, scale, cbits);
+                                              uint32_t& nhit_lane, float* D, float* Dc, uint32_t* fb_hits, double scale, uint32_t cbits) {
+    // A scan is bound by instruction issue (~0.46 ns per record and workgroup whether the record is 12 or 20 bytes,
+    // profiles/r02_owner_experiments.txt), and most workgroups hit with few of their records: the hits are counted per lane
+    // (one add with the compare's mask as carry) and the fixed-point form of dw is only made for a record that hits.
+    bool hit[NI];
+    bool any = false;
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
-        const uint32_t rel = idx[j], local = rel - lo_rel;
-        const bool hit = valid && local < sl.size;
-        if (hit) {
-            if (FIXED)
-                atomicAdd(reinterpret_cast<unsigned long long*>(acc) + local, fixed);
-            else
-                atomicAdd(&acc[local], dw);
-        }
-        nhit_wave += (uint32_t)__popcll(__ballot(hit));         // scalar unit
-        if (FB && valid && !hit) {
-            const uint32_t ch = rel >> sl.cshift;
-            if ((sl.fb_mask >> ch) & 1u) {
-                __hip_atomic_fetch_add(&D[sl.orb_dlo + rel], dw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (Dc) __hip_atomic_fetch_add(&Dc[sl.orb_dlo + rel], 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                atomicAdd(&fb_hits[ch], 1u);            // LDS counter, flushed once per workgroup
+        hit[j] = valid && idx[j] - lo_rel < sl.size;
+        any |= hit[j];
+        nhit_lane += hit[j] ? 1u : 0u;
+    }
+    if (any) {
+        unsigned long long fixed = 0;
+        if (FIXED) fixed = packed_add(dw, scale, cbits);
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+            if (hit[j]) {
+                const uint32_t local = idx[j] - lo_rel;
+                if (FIXED)
+                    atomicAdd(reinterpret_cast<unsigned long long*>(acc) + local, fixed);
+                else
+                    atomicAdd(&acc[local], dw);
             }
-        }
+    }
+    if (FB && valid) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+            if (!hit[j]) {
+                const uint32_t rel = idx[j], ch = rel >> sl.cshift;
+                if ((sl.fb_mask >> ch) & 1u) {
+                    __hip_atomic_fetch_add(&D[sl.orb_dlo + rel], dw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (Dc) __hip_atomic_fetch_add(&Dc[sl.orb_dlo + rel], 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    atomicAdd(&fb_hits[ch], 1u);            // LDS counter, flushed once per workgroup
+                }
+            }
     }
 }
 
@@ -1369,9 +1383,9 @@ __device__ __forceinline__ void own_run(float* acc, const Slice& s, const TdRecs
         }
     }
     // load statistics for the planner: one counter bump per wave
+    nhit += nhit_wave;              // (both are per-lane counts)
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) nhit += __shfl_down(nhit, off);
-    nhit += nhit_wave;
     if ((threadIdx.x & 63) == 0 && nhit) atomicAdd(&hits[s.chunk], nhit);
 }
 
