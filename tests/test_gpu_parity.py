@@ -353,12 +353,16 @@ def test_td_hot_set_path_vs_oracle(n, B, monkeypatch):
     eng.close()
 
 
+@pytest.mark.parametrize('lag', [2, 0])
 @pytest.mark.parametrize('n', [4, 5, 6])
-def test_lane_sort_is_invisible(n, monkeypatch):
+def test_lane_sort_is_invisible(n, lag, monkeypatch):
     """g2048_set_lane_sort: lanes re-ordered by their big-tile pattern every few steps (k_td_play reads them through the
     sorted permutation).  Every step is still the oracle's step, lane for lane (the accessors restore the identity
-    order), including lanes that finish (auto-reset off: DONE lanes travel with the others)."""
+    order), including lanes that finish (auto-reset off: DONE lanes travel with the others).  lag 2 (the default): the
+    sort runs on a side stream and is applied two steps after the boards it looked at — an accessor in between drops it;
+    lag 0: sorted in line."""
     monkeypatch.setenv('G2048_SORT_MIN', '1')
+    monkeypatch.setenv('G2048_SORT_LAG', str(lag))
     B = 3000
     eng = Engine(B, n=n, seed=600 + n)
     eng.set_auto_reset(False)
@@ -366,7 +370,7 @@ def test_lane_sort_is_invisible(n, monkeypatch):
     eng.step_random(80)                                      # late enough for big tiles and for some games to be over
     for t in range(5):
         helpers.check_td_step(eng, n, formulas.exact_alpha(n), formulas.weights(n, scale=2.0 ** -(4 + t)))
-    eng.td_steps(formulas.exact_alpha(n) * 2.0 ** -12, 4)    # two re-orderings on top of each other, no accessor in between
+    eng.td_steps(formulas.exact_alpha(n) * 2.0 ** -12, 9)    # re-orderings on top of each other, no accessor in between
     # (a small alpha: the table of the last check stays in place here, and 3000 lanes at the per-game alpha would blow it up)
     helpers.check_td_step(eng, n, formulas.exact_alpha(n), formulas.weights(n, scale=2.0 ** -5))
     eng.close()
