@@ -2104,6 +2104,7 @@ struct g2048_ctx {
         uint32_t sort_min_batch = 1u << 17;     // smaller batches keep their lane order
         uint32_t sort_lag = 2;          // steps between the boards a sort looks at and the step that applies it (G2048_SORT_LAG; 0 = sort in line)
         int hex_bins = 1;               // n = 6: f_6 orbits through k_hex_* (0: k_td_update_tail's scattered atomics)
+        int delta_accum = 0;            // multi-GPU epoch delta: 0 = W - W0 when it is asked for, 1 = every add of a step mirrored in an accumulator
         int mean_one_pass = 1;          // per-slot mean rule: counts packed beside the sums (0: always two accumulation passes)
         int play_hot = 0;               // 1: k_td_play reads the hot four-cell tuples from an LDS copy (n >= 4, big batches); measured, not faster
         uint32_t play_hot_min = 1u << 16;   // smallest batch that takes that path (a workgroup copies 88 KB per launch)
@@ -2201,6 +2202,7 @@ void read_knobs(g2048_ctx* c) {
     if (const char* e = getenv("G2048_SORT_EVERY")) k.sort_every = (uint32_t)atoi(e);
     if (const char* e = getenv("G2048_SORT_MIN")) k.sort_min_batch = (uint32_t)atoi(e);
     if (const char* e = getenv("G2048_SORT_LAG")) k.sort_lag = (uint32_t)atoi(e);
+    if (const char* e = getenv("G2048_DELTA_ACCUM")) k.delta_accum = atoi(e);
     if (const char* e = getenv("G2048_PLAY_HOT_MIN")) k.play_hot_min = (uint32_t)atoi(e);
 }
 
@@ -2918,7 +2920,7 @@ int launch_td_step(g2048_ctx* c, float alpha, hipEvent_t ev = nullptr, hipEvent_
         float* Doth = alt ? c->D : c->D2;
         float* Ccur = alt ? c->Dcnt2 : c->Dcnt;
         float* Coth = alt ? c->Dcnt : c->Dcnt2;
-        float* dacc = c->tracking ? c->delta : nullptr;
+        float* dacc = c->tracking && c->knob.delta_accum ? c->delta : nullptr;
         // Mean rule: counts and sums come from ONE accumulation (count bits packed under the fixed-point sums) while the
         // count field leaves the sums 2^-18 of the largest |dw| as resolution: fewer than 2^21 adds per slot and workgroup
         // (the planner keeps the record ranges that short).
@@ -2972,7 +2974,7 @@ int launch_td_step(g2048_ctx* c, float alpha, hipEvent_t ev = nullptr, hipEvent_
         }
         if (c->n >= 4) c->dpar ^= 1u;
     } else {
-        BY_N(c, (k_td_update<N><<<grid_for((uint64_t)B * 16), WG, 0, c->stream>>>(c->w, c->tracking ? c->delta : nullptr, recs, B)));
+        BY_N(c, (k_td_update<N><<<grid_for((uint64_t)B * 16), WG, 0, c->stream>>>(c->w, c->tracking && c->knob.delta_accum ? c->delta : nullptr, recs, B)));
         if (ev_owner) (void)hipEventRecord(ev_owner, c->stream);
         if (ev_tail) (void)hipEventRecord(ev_tail, c->stream);
     }
@@ -3470,7 +3472,7 @@ int g2048_update(g2048_ctx* c, const uint8_t* states, const float* dw, int64_t c
     float* d_dw = (float*)((char*)c->scratch + n * 16);
     int rc;
     if ((rc = h2d(c, d_states, states, n * 16)) || (rc = h2d(c, d_dw, dw, n * 4))) return rc;
-    BY_N(c, (k_update_records<N><<<grid_for(n * 8), WG, 0, c->stream>>>(c->w, c->tracking ? c->delta : nullptr, d_states, d_dw, (uint32_t)n)));
+    BY_N(c, (k_update_records<N><<<grid_for(n * 8), WG, 0, c->stream>>>(c->w, c->tracking && c->knob.delta_accum ? c->delta : nullptr, d_states, d_dw, (uint32_t)n)));
     if ((rc = launched(c, "k_update_records"))) return rc;
     return g2048_sync(c);
 }
@@ -3730,6 +3732,16 @@ static int ensure_pack(g2048_ctx* c, size_t count) {
     return G2048_OK;
 }
 
+// The epoch's delta D = W - W0, formed when somebody asks for it (one pass over the table per epoch).  Round 2 first kept
+// D as an accumulator that every add of every step was mirrored into (G2048_DELTA_ACCUM=1 still does): two scattered
+// read-modify-writes instead of one in the apply kernels, 5 % of a step at n = 5 — which a job of N > 1 ranks paid and the
+// one-rank run it is compared with did not.  Both give the same D up to the rounding W itself has taken.
+static int refresh_delta(g2048_ctx* c) {
+    if (c->knob.delta_accum) return G2048_OK;
+    k_delta_sub<<<2048, WG, 0, c->stream>>>(c->w, c->w0, c->delta, c->slots);
+    return launched(c, "k_delta_sub");
+}
+
 int g2048_delta_begin(g2048_ctx* c) {
     if (!c) return G2048_ERR_ARG;
     NEED_TABLE(c);
@@ -3749,6 +3761,7 @@ int g2048_delta_extract(g2048_ctx* c, void* dst) {
     if (!c->tracking) return fail(c, G2048_ERR_STATE, "g2048_delta_begin was not called");
     if (int rc = bind(c)) return rc;
     USE_TABLE(c);
+    if (int rc = refresh_delta(c)) return rc;
     if (dst) {
         k_delta_out<<<2048, WG, 0, c->stream>>>(c->delta, (float*)dst, c->slots, c->placed);
         if (int rc = launched(c, "k_delta_out")) return rc;
@@ -3763,6 +3776,8 @@ int g2048_delta_apply(g2048_ctx* c, const void* src) {
     if (!c->tracking) return fail(c, G2048_ERR_STATE, "g2048_delta_begin was not called");
     if (int rc = bind(c)) return rc;
     USE_TABLE(c);
+    if (!src)
+        if (int rc = refresh_delta(c)) return rc;
     k_delta_add<<<2048, WG, 0, c->stream>>>(c->w, c->w0, src ? (const float*)src : c->delta, c->delta, c->slots, src ? c->placed : 0);
     if (int rc = launched(c, "k_delta_add")) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -3787,6 +3802,7 @@ int g2048_delta_pack_touched(g2048_ctx* c, void* pack) {
     if (!c->tracking) return fail(c, G2048_ERR_STATE, "g2048_delta_begin was not called");
     if (int rc = bind(c)) return rc;
     USE_TABLE(c);
+    if (int rc = refresh_delta(c)) return rc;
     k_delta_pack_touched<<<2048, WG, 0, c->stream>>>(c->delta, (float*)pack, c->slots, c->placed);
     if (int rc = launched(c, "k_delta_pack_touched")) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -3896,6 +3912,7 @@ int g2048_allreduce_deltas(g2048_ctx* c) {
     USE_TABLE(c);
     Rccl* r = rccl();
     const size_t n = c->slots;
+    if (int rc = refresh_delta(c)) return rc;
     if (c->update_rule == 1) {
         if (int rc = ensure_pack(c, 2 * n)) return rc;
         k_delta_pack_touched<<<2048, WG, 0, c->stream>>>(c->delta, c->pack, n, 0);

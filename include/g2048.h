@@ -180,9 +180,9 @@ int g2048_stats_reset(g2048_ctx* ctx);
 
 /* ---- multi-GPU (the reference trains in one Python thread, r_learning.py:269-296, application.py:611).
  * One process and one context per GPU.  Episodes are sharded by lane0 (no data-path collective); the table is replicated.
- * An epoch is E board-steps; g2048_delta_begin starts the first one (W0 = W) and from then on every add a step makes to
- * the table is mirrored in an fp32 accumulator D (the delta is accumulated, not recovered as W - W0).  At the end of an
- * epoch the ranks exchange D with ONE sum all-reduce over xGMI and every replica becomes
+ * An epoch is E board-steps; g2048_delta_begin starts the first one (W0 = W); the epoch's delta is D = W - W0, formed when
+ * it is asked for (G2048_DELTA_ACCUM=1 in the environment: an fp32 accumulator that mirrors every add instead).  At the end
+ * of an epoch the ranks exchange D with ONE sum all-reduce over xGMI and every replica becomes
  *     rule 0 (sum):   W = W0 + sum_r D_r
  *     rule 1 (mean):  W = W0 + sum_r D_r / max(1, #{r : D_r != 0})   per slot — the mean over the ranks that moved the slot
  *                     (the payload is [D | touched], twice the table)
