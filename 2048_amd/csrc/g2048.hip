@@ -2005,7 +2005,7 @@ __global__ __launch_bounds__(WG) void k_delta_add_mean(float* w, float* w0, cons
         float v = w0[p] + (n > 1.0f ? pack[i] / n : pack[i]);
         w[p] = v;
         w0[p] = v;
-        dacc[p] = 0.0f;
+        if (dacc) dacc[p] = 0.0f;
     }
 }
 
@@ -3778,7 +3778,7 @@ int g2048_delta_apply(g2048_ctx* c, const void* src) {
     USE_TABLE(c);
     if (!src)
         if (int rc = refresh_delta(c)) return rc;
-    k_delta_add<<<2048, WG, 0, c->stream>>>(c->w, c->w0, src ? (const float*)src : c->delta, c->delta, c->slots, src ? c->placed : 0);
+    k_delta_add<<<2048, WG, 0, c->stream>>>(c->w, c->w0, src ? (const float*)src : c->delta, c->knob.delta_accum ? c->delta : nullptr, c->slots, src ? c->placed : 0);
     if (int rc = launched(c, "k_delta_add")) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return G2048_OK;
@@ -3790,7 +3790,7 @@ int g2048_delta_apply_mean(g2048_ctx* c, const void* pack) {
     if (!c->tracking) return fail(c, G2048_ERR_STATE, "g2048_delta_begin was not called");
     if (int rc = bind(c)) return rc;
     USE_TABLE(c);
-    k_delta_add_mean<<<2048, WG, 0, c->stream>>>(c->w, c->w0, (const float*)pack, c->delta, c->slots, c->placed);
+    k_delta_add_mean<<<2048, WG, 0, c->stream>>>(c->w, c->w0, (const float*)pack, c->knob.delta_accum ? c->delta : nullptr, c->slots, c->placed);
     if (int rc = launched(c, "k_delta_add_mean")) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return G2048_OK;
@@ -3918,12 +3918,12 @@ int g2048_allreduce_deltas(g2048_ctx* c) {
         k_delta_pack_touched<<<2048, WG, 0, c->stream>>>(c->delta, c->pack, n, 0);
         ncclResult_t e = r->AllReduce(c->pack, c->pack, 2 * n, ncclFloat32, ncclSum, (ncclComm_t)c->comm, c->stream);
         if (e != ncclSuccess) return rccl_fail(c, "ncclAllReduce", e);
-        k_delta_add_mean<<<2048, WG, 0, c->stream>>>(c->w, c->w0, c->pack, c->delta, n, 0);
+        k_delta_add_mean<<<2048, WG, 0, c->stream>>>(c->w, c->w0, c->pack, c->knob.delta_accum ? c->delta : nullptr, n, 0);
     } else {
         if (int rc = ensure_pack(c, n)) return rc;
         ncclResult_t e = r->AllReduce(c->delta, c->pack, n, ncclFloat32, ncclSum, (ncclComm_t)c->comm, c->stream);
         if (e != ncclSuccess) return rccl_fail(c, "ncclAllReduce", e);
-        k_delta_add<<<2048, WG, 0, c->stream>>>(c->w, c->w0, c->pack, c->delta, n, 0);
+        k_delta_add<<<2048, WG, 0, c->stream>>>(c->w, c->w0, c->pack, c->knob.delta_accum ? c->delta : nullptr, n, 0);
     }
     return launched(c, "g2048_allreduce_deltas");
 }
