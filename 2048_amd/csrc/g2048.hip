@@ -838,13 +838,7 @@ __global__ __launch_bounds__(TPB, G2048_PLAY_MIN_WAVES) void k_td_play(LaneSet i
     const uint32_t lane = threadIdx.x & 63u;
     // (wave-uniform by construction; readfirstlane tells the compiler, so that block numbers live in SGPRs and the loop's
     // exits are scalar branches)
-#ifdef G2048_EXP_CU_PAIRS        // (experiment: the two workgroups a CU holds — blockIdx b and b + grid / 2 — take neighbouring blocks)
-    const uint32_t half_ = gridDim.x >> 1;
-    const uint32_t wg_ = (gridDim.x & 1u) || half_ == 0 ? blockIdx.x : (blockIdx.x % half_) * 2u + blockIdx.x / half_;
-    const uint32_t nwaves = gridDim.x * WAVES, wave_id = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wg_ * WAVES + (threadIdx.x >> 6)));
-#else
     const uint32_t nwaves = gridDim.x * WAVES, wave_id = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * WAVES + (threadIdx.x >> 6)));
-#endif
     const uint32_t nblocks = (B + 63u) / 64u;
     const uint32_t dyn0 = static_rounds * nwaves < nblocks ? static_rounds * nwaves : nblocks;     // first block of the dynamic region
 #ifdef G2048_EXP_SEG_XCD        // (experiment: the workgroups that share a counter sit on one XCD)
