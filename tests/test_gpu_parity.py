@@ -417,12 +417,14 @@ def test_lane_sort_same_games_at_scale():
     assert a[4]['moves'] == b[4]['moves'] == B * steps and abs(a[4]['episodes'] - b[4]['episodes']) <= 64
 
 
-def test_td_config4_full_size_owner_path():
-    """BASELINE config 4 at its full size — 2^20 lanes, n = 5, the LDS-owner update the bench times.  Per step:
+@pytest.mark.parametrize('n', [5, 6])
+def test_td_config4_full_size_owner_path(n):
+    """BASELINE config 4 at its full size — 2^20 lanes, n = 5, the LDS-owner update the bench times — and the per-GPU
+    workload of config 5 (n = 6: the binned f_6 update on top of it).  Per step:
     a slice of lanes is replayed by the float64 oracle (their choices depend only on the table before the step: boards,
     scores, RNG, carried state and labels bit for bit), every live lane moves once, and the table's total change equals
     8 F sum(dw) with the records' dw rebuilt from the lanes' exported state (r_learning.py:240,248)."""
-    n, B, F = 5, 1 << 20, 21
+    B, F = 1 << 20, {5: 21, 6: 33}[n]
     alpha = formulas.exact_alpha(n)
     eng = Engine(B, n=n, seed=4)
     eng.set_auto_reset(False)
