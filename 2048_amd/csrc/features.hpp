@@ -35,19 +35,19 @@ constexpr uint32_t HEX_SIZE = 7529536u;                         // 14^6
 // ---- where a table entry lives in device memory (n >= 4, the four- and five-cell tables)
 // A board's index into a four-cell table is four nibbles, and tiles are small: bits 2 and 3 of a nibble hardly vary.  In
 // index order a 128-byte cache line holds one cell's whole nibble plus one bit of the next, so the entries a batch of boards
-// reads are spread thinly over many lines, and — the tables being 256 KB apart — the busy lines of all 17 tables fall on
-// the same few cache sets and L2 channels.  In memory the low 16 index bits are therefore stored 4 x 4 bit-TRANSPOSED
+// reads are spread thinly over many lines.  In memory the low 16 index bits are therefore stored 4 x 4 bit-TRANSPOSED
 // ([bit 3 of the four cells | bit 2 .. | bit 1 .. | bit 0 ..]: a line now holds the entries that differ in the cells' low
-// bits), and bits 5..10 are rotated by a per-table constant.  Both steps are bijections of a 65 536-entry block, so every
-// consumer of the table goes through table_place(); the ABI (g2048_weights_get / _set, the delta buffers, feature
-// indices) stays in the reference's order.  Measured: k_td_play 0.168 -> 0.145 ms.
+// bits; the map is its own inverse).  Every consumer of the table goes through table_place(); the ABI
+// (g2048_weights_get / _set, the delta buffers, feature indices) stays in the reference's order.  Measured: k_td_play
+// 0.168 -> 0.156 ms.  (A per-table rotation of index bits 5..10 on top of it — the tables are 256 KB
+// apart, so their busy lines share cache sets — looked good in a timing-only build and costs 1-2 % in the real one:
+// profiles/r02_knob_ab.txt.)
 G2048_HD uint32_t table_place(uint32_t slot) {
     uint32_t x = slot & 0xFFFFu;
     uint32_t t = (x ^ (x >> 3)) & 0x0A0Au;
     x ^= t ^ (t << 3);
     t = (x ^ (x >> 6)) & 0x00CCu;
     x ^= t ^ (t << 6);
-    x ^= ((slot >> 16) * 0x9E5u) & 0x07E0u;
     return (slot & ~0xFFFFu) | x;
 }
 
