@@ -42,14 +42,15 @@ constexpr uint32_t HEX_SIZE = 7529536u;                         // 14^6
 // 0.168 -> 0.156 ms.  (A per-table rotation of index bits 5..10 on top of it — the tables are 256 KB
 // apart, so their busy lines share cache sets — looked good in a timing-only build and costs 1-2 % in the real one:
 // profiles/r02_knob_ab.txt.)
-G2048_HD uint32_t table_place(uint32_t slot) {
-    uint32_t x = slot & 0xFFFFu;
+G2048_HD uint32_t bit_transpose16(uint32_t v) {       // the low 16 bits as a 4 x 4 bit matrix, transposed; upper bits unchanged
+    uint32_t x = v & 0xFFFFu;
     uint32_t t = (x ^ (x >> 3)) & 0x0A0Au;
     x ^= t ^ (t << 3);
     t = (x ^ (x >> 6)) & 0x00CCu;
     x ^= t ^ (t << 6);
-    return (slot & ~0xFFFFu) | x;
+    return (v & ~0xFFFFu) | x;
 }
+G2048_HD uint32_t table_place(uint32_t slot) { return bit_transpose16(slot); }
 
 G2048_HD uint32_t pack16(uint32_t w) {      // bytes b0..b3 (cells 0..3 of a line) -> b0<<12|b1<<8|b2<<4|b3
     return ((w & 0xFu) << 12) | ((w >> 8 & 0xFu) << 8) | ((w >> 16 & 0xFu) << 4) | (w >> 24 & 0xFu);

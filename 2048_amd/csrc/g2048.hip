@@ -480,7 +480,7 @@ __device__ __forceinline__ Choice choose(const float* __restrict__ w, const Move
     }
     if (c.action < 0 && first_valid >= 0) {     // every value was -inf or NaN (a poisoned table): still make a legal move
         c.action = first_valid;
-        c.value = c.v[first_valid];
+        c.value = first_valid == 0 ? c.v[0] : first_valid == 1 ? c.v[1] : first_valid == 2 ? c.v[2] : c.v[3];      // (no dynamic index: it would put v[] in scratch or LDS)
     }
     return c;
 }
@@ -491,63 +491,76 @@ __device__ __forceinline__ Choice choose(const float* __restrict__ w, const Move
 // <= 32 (6^4 = 1 296 of a feature's 65 536 entries).  Those 17 x 1 296 entries (88 KB) are copied into LDS once per
 // launch and read from there; the LDS takes divergent lanes about ten times faster than the L1's tag path, and the L1
 // keeps its lines for the cold tail.
-constexpr uint32_t HOT_PER_FEATURE = 1296u, HOT_FEATURES = 17u, HOT_SLOTS = HOT_FEATURES * HOT_PER_FEATURE;
-constexpr int PLAY_HOT_WG = 768;        // one workgroup per CU shares the 88 KB copy (3 waves per SIMD, as before)
+#ifndef G2048_HOT_ENTRIES        // entries per four-cell table kept in LDS: the first ones in the table's memory order (a power of two)
+#define G2048_HOT_ENTRIES 2048
+#endif
+constexpr uint32_t HOT_PER_FEATURE = G2048_HOT_ENTRIES, HOT_FEATURES = 17u, HOT_SLOTS = HOT_FEATURES * HOT_PER_FEATURE;
+constexpr int PLAY_HOT_WG = 512;        // one workgroup per CU shares the copy (two waves per SIMD, as without it)
 
-// every nibble of the 16-bit index <= 5
-__device__ __forceinline__ bool hot4(uint32_t idx) { return ((idx | (idx + 0x2222u)) & 0x8888u) == 0u; }
-// base-16 digits n0 n1 n2 n3 (all <= 5) -> ((n0 * 6 + n1) * 6 + n2) * 6 + n3
-__device__ __forceinline__ uint32_t compact6(uint32_t idx) {
-    const uint32_t t = idx >> 8, b = idx & 0xFFu;
-    const uint32_t p = t - 10u * (t >> 4), q = b - 10u * (b >> 4);
-    return p * 36u + q;
-}
-__device__ __forceinline__ uint32_t expand6(uint32_t k) {
-    return ((k / 216u) << 12) | (((k / 36u) % 6u) << 8) | (((k / 6u) % 6u) << 4) | (k % 6u);
-}
-
+// In the table's memory order (table_place) the entries of small tiles come first: transposed index t < 256 = every cell of
+// the tuple empty / 2 / 4 / 8, t < 1 024 = 45 % of a fresh agent's gathers and 33 % of a trained agent's
+// (tools/hot_coverage.py).  So "hot" is one compare on a number the gather computes anyway and t is the LDS index.
 template <int TPB>
 __device__ __forceinline__ void load_hot_set(float* hot, const float* __restrict__ w) {
     for (uint32_t j = threadIdx.x; j < HOT_SLOTS; j += TPB) {
-        const uint32_t f = j / HOT_PER_FEATURE, k = j - f * HOT_PER_FEATURE;
-        hot[j] = w[table_place(f * 65536u + expand6(k))];
+        const uint32_t f = j / HOT_PER_FEATURE, t = j - f * HOT_PER_FEATURE;
+        hot[j] = w[f * 65536u + t];
     }
     __syncthreads();
 }
 
-// One table entry of a four-cell feature f (slot = f * 65536 + idx): from the LDS copy when the tuple is hot, else from
-// memory — ONE flat load whose lanes point into either aperture, so there is no second result register and no branch.
-__device__ __forceinline__ float ld_quad(const float* __restrict__ w, const float* hot, uint32_t f, uint32_t slot, bool use) {
-    const uint32_t idx = slot & 0xFFFFu;
-    const bool h = hot4(idx);
-    const float* p = h ? hot + (f * HOT_PER_FEATURE + compact6(idx)) : w + table_place(slot);
-    p = use ? p : hot;                  // directions that do not change the board read one fixed LDS word
-    return *p;
-}
-
-// choose<N> with the hot set (n >= 4: features 0..16 are the four-cell tuples)
+// choose<N> with the hot set (n >= 4: features 0..16 are the four-cell tuples), in two phases so that no gather needs a
+// second result register and none waits for another: (A) EVERY lane reads the LDS copy at t mod HOT (a wrong word for the
+// cold lanes, at LDS speed); (B) the cold lanes then overwrite it with a global load under their exec mask.  The L1 sees
+// the cold lanes only.  (Round 2's first version — every cell <= 32 through a base-6 index, ONE flat load per gather whose
+// lanes point into either aperture — removed 44 % of the L1's tag look-ups and no time: a flat load still walks every lane
+// through the address unit and the tag stage.  A ds_read / global_load pair under complementary exec masks, LDS second,
+// makes the compiler wait for each global load before it issues the ds_read into the same register.)
 template <int N>
-__device__ __forceinline__ Choice choose_hot(const float* __restrict__ w, const float* hot, const Moves4& mv) {
+__device__ __forceinline__ Choice choose_hot(const float* __restrict__ w, const float* hot_, const Moves4& mv) {
     constexpr int F = Shape<N>::F;
     static_assert(N >= 4, "the hot set covers the four-cell features");
+    // (`hot_` IS the kernel's __shared__ array, which the compiler cannot see through the lambda it arrives by: ds_read, not flat)
+    const __attribute__((address_space(3))) float* hot = (const __attribute__((address_space(3))) float*)hot_;
     Choice c;
     c.action = -1;
     c.value = -INFINITY;
     int first_valid = -1;
-#define G2048_HOT_DIR(M, X)                                                                 \
+#define G2048_HOT_A(M, X, T, MS)                                                            \
     float X[F];                                                                             \
+    uint32_t T[17], MS[F];                                                                  \
     {                                                                                       \
-        uint32_t s[F], ms[F];           /* index order for the hot test, memory order for the rest */ \
+        uint32_t s[F];                                                                      \
         feature_slots<N>(pack_board((M).after), s);                                         \
-        memory_slots<N>(pack_board((M).after), ms);                                         \
-        _Pragma("unroll") for (int f = 0; f < 17; ++f) X[f] = ld_quad(w, hot, (uint32_t)f, s[f], (M).changed); \
-        _Pragma("unroll") for (int f = 17; f < F; ++f) X[f] = ld_w(w, (M).changed ? ms[f] : 0u);               \
+        memory_slots<N>(pack_board((M).after), MS);         /* (used for the features behind the four-cell ones) */ \
+        _Pragma("unroll") for (int f = 0; f < 17; ++f) {                                    \
+            T[f] = bit_transpose16(s[f] & 0xFFFFu);                                         \
+            X[f] = hot[(uint32_t)f * HOT_PER_FEATURE + (T[f] & (HOT_PER_FEATURE - 1u))];   \
+        }                                                                                   \
     }
+    /* The masked load is inline asm: as C, the compiler merges "loaded" and "not loaded" at the end of the branch and waits  \
+       for the load right there (84 gathers going out one at a time).  It therefore does not know that X[f] is in flight:       \
+       G2048_HOT_FENCE below waits for the memory queue and names every X[f], so that no use can be scheduled above it. */       \
+#define G2048_HOT_B(M, X, T, MS)                                                            \
+    _Pragma("unroll") for (int f = 0; f < 17; ++f)                                          \
+        if ((M).changed && T[f] >= HOT_PER_FEATURE) {                                       \
+            const uint32_t off_ = ((uint32_t)f * 65536u + T[f]) << 2;                       \
+            asm volatile("global_load_dword %0, %1, %2" : "+v"(X[f]) : "v"(off_), "s"(w)); \
+        }                                                                                   \
+    _Pragma("unroll") for (int f = 17; f < F; ++f) X[f] = ld_w(w, (M).changed ? MS[f] : 0u);
+#define G2048_HOT_FENCE(X)                                                                  \
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(X[0]), "+v"(X[1]), "+v"(X[2]), "+v"(X[3]), "+v"(X[4]), "+v"(X[5]), "+v"(X[6]), "+v"(X[7]), "+v"(X[8]), \
+                 "+v"(X[9]), "+v"(X[10]), "+v"(X[11]), "+v"(X[12]), "+v"(X[13]), "+v"(X[14]), "+v"(X[15]), "+v"(X[16]));
     if constexpr (F <= G2048_BATCH4_MAXF) {
-        G2048_HOT_DIR(mv.m0, x0)
-        G2048_HOT_DIR(mv.m1, x1)
-        G2048_HOT_DIR(mv.m2, x2)
-        G2048_HOT_DIR(mv.m3, x3)
+        G2048_HOT_A(mv.m0, x0, t0, q0)
+        G2048_HOT_B(mv.m0, x0, t0, q0)
+        G2048_HOT_A(mv.m1, x1, t1, q1)
+        G2048_HOT_B(mv.m1, x1, t1, q1)
+        G2048_HOT_A(mv.m2, x2, t2, q2)
+        G2048_HOT_B(mv.m2, x2, t2, q2)
+        G2048_HOT_A(mv.m3, x3, t3, q3)
+        G2048_HOT_B(mv.m3, x3, t3, q3)
+        G2048_HOT_FENCE(x0) G2048_HOT_FENCE(x1) G2048_HOT_FENCE(x2) G2048_HOT_FENCE(x3)
         float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f, v3 = 0.0f;      // each a left-to-right sum, as QAgent.evaluate
 #pragma unroll
         for (int f = 0; f < F; ++f) {
@@ -562,8 +575,11 @@ __device__ __forceinline__ Choice choose_hot(const float* __restrict__ w, const 
         c.v[3] = mv.m3.changed ? v3 : -INFINITY;
     } else {
         {
-            G2048_HOT_DIR(mv.m0, x0)
-            G2048_HOT_DIR(mv.m1, x1)
+            G2048_HOT_A(mv.m0, x0, t0, q0)
+            G2048_HOT_B(mv.m0, x0, t0, q0)
+            G2048_HOT_A(mv.m1, x1, t1, q1)
+            G2048_HOT_B(mv.m1, x1, t1, q1)
+            G2048_HOT_FENCE(x0) G2048_HOT_FENCE(x1)
             float v0 = 0.0f, v1 = 0.0f;
 #pragma unroll
             for (int f = 0; f < F; ++f) {
@@ -574,8 +590,11 @@ __device__ __forceinline__ Choice choose_hot(const float* __restrict__ w, const 
             c.v[1] = mv.m1.changed ? v1 : -INFINITY;
         }
         {
-            G2048_HOT_DIR(mv.m2, x2)
-            G2048_HOT_DIR(mv.m3, x3)
+            G2048_HOT_A(mv.m2, x2, t2, q2)
+            G2048_HOT_B(mv.m2, x2, t2, q2)
+            G2048_HOT_A(mv.m3, x3, t3, q3)
+            G2048_HOT_B(mv.m3, x3, t3, q3)
+            G2048_HOT_FENCE(x2) G2048_HOT_FENCE(x3)
             float v2 = 0.0f, v3 = 0.0f;
 #pragma unroll
             for (int f = 0; f < F; ++f) {
@@ -586,7 +605,9 @@ __device__ __forceinline__ Choice choose_hot(const float* __restrict__ w, const 
             c.v[3] = mv.m3.changed ? v3 : -INFINITY;
         }
     }
-#undef G2048_HOT_DIR
+#undef G2048_HOT_A
+#undef G2048_HOT_B
+#undef G2048_HOT_FENCE
     const bool ch[4] = {mv.m0.changed, mv.m1.changed, mv.m2.changed, mv.m3.changed};
 #pragma unroll
     for (int d = 0; d < 4; ++d)
@@ -599,7 +620,7 @@ __device__ __forceinline__ Choice choose_hot(const float* __restrict__ w, const 
         }
     if (c.action < 0 && first_valid >= 0) {     // every value was -inf or NaN (a poisoned table): still make a legal move
         c.action = first_valid;
-        c.value = c.v[first_valid];
+        c.value = first_valid == 0 ? c.v[0] : first_valid == 1 ? c.v[1] : first_valid == 2 ? c.v[2] : c.v[3];      // (no dynamic index: it would put v[] in scratch or LDS)
     }
     return c;
 }
@@ -2106,7 +2127,7 @@ struct g2048_ctx {
         int hex_bins = 1;               // n = 6: f_6 orbits through k_hex_* (0: k_td_update_tail's scattered atomics)
         int delta_accum = 0;            // multi-GPU epoch delta: 0 = W - W0 when it is asked for, 1 = every add of a step mirrored in an accumulator
         int mean_one_pass = 1;          // per-slot mean rule: counts packed beside the sums (0: always two accumulation passes)
-        int play_hot = 0;               // 1: k_td_play reads the hot four-cell tuples from an LDS copy (n >= 4, big batches); measured, not faster
+        int play_hot = 1;               // k_td_play reads the first entries of every four-cell table (memory order) from an LDS copy (n >= 4, big batches): -8 % per step
         uint32_t play_hot_min = 1u << 16;   // smallest batch that takes that path (a workgroup copies 88 KB per launch)
     } knob;
     std::vector<double> load;           // smoothed adds per step per chunk
