@@ -2128,7 +2128,7 @@ struct g2048_ctx {
         int delta_accum = 0;            // multi-GPU epoch delta: 0 = W - W0 when it is asked for, 1 = every add of a step mirrored in an accumulator
         int mean_one_pass = 1;          // per-slot mean rule: counts packed beside the sums (0: always two accumulation passes)
         int play_hot = 1;               // k_td_play reads the first entries of every four-cell table (memory order) from an LDS copy (n >= 4, big batches): -8 % per step
-        uint32_t play_hot_min = 1u << 16;   // smallest batch that takes that path (a workgroup copies 88 KB per launch)
+        uint32_t play_hot_min = 1u << 18;   // smallest batch that takes that path (a workgroup copies 136 KB per launch: break-even at 2^17 lanes)
     } knob;
     std::vector<double> load;           // smoothed adds per step per chunk
     std::vector<double> work;           // measured workgroup time x workgroups per chunk (clock ticks; 0 = not measured yet)

@@ -326,7 +326,7 @@ def main():
                               'GBps': by_play * B / (ms_play * 1e-3) / 1e9, 'frac': by_play * B / (ms_play * 1e-3) / 1e9 / HBM_PEAK_GBS,
                               # its own bound is not HBM: 4 x num_feat divergent 4-byte gathers per lane, one cache line per
                               # cycle through each CU's address path
-                              'limited_by': 'L1 misses of the table gathers served by L2 (the table is cache-resident), behind ~0.1 ms of per-block latency; DESIGN.md section 4'},
+                              'limited_by': 'L1 misses of the cold table gathers served by L2 (the table is cache-resident; the hot entries come from LDS), VALU issue and per-block latency; DESIGN.md section 4'},
                 'whole_step': {'algorithmic_bytes': (by_play + by_update) * B, 'ms': ms_step,
                                'GBps': (by_play + by_update) * B / (ms_step * 1e-3) / 1e9,
                                'frac': (by_play + by_update) * B / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS},

@@ -333,8 +333,9 @@ def test_td_large_batch_vs_oracle_through_replans():
 
 @pytest.mark.parametrize('n,B', [(4, 4096), (5, 5000), (6, 1237)])
 def test_td_hot_set_path_vs_oracle(n, B, monkeypatch):
-    """k_td_play's LDS hot set (four-cell tuples with all tiles <= 32 served from an LDS copy through flat loads) forced
-    on at a small batch: mid-game boards mix hot and cold tuples, random boards of tiles 0..13 are almost all cold; every
+    """k_td_play's LDS hot set (the first 2 048 entries of every four-cell table in memory order — small tiles — read from
+    an LDS copy; the other lanes' gathers issued under their exec mask through an asm load; on by default from 2^18 lanes)
+    forced on at a small batch: mid-game boards mix hot and cold tuples, random boards of tiles 0..13 are almost all cold; every
     step is checked against the float64 oracle as everywhere else."""
     monkeypatch.setenv('G2048_PLAY_HOT_MIN', '1')
     eng = Engine(B, n=n, seed=900 + n)

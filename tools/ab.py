@@ -19,7 +19,7 @@ CHILD = r'''
 import importlib, json, os, sys
 sys.path.insert(0, %r)
 pkg = importlib.import_module('2048_amd')
-n, B = int(os.environ.get('N', 5)), 1 << 20
+n, B = int(os.environ.get('N', 5)), int(os.environ.get('B', 1 << 20))
 eng = pkg.Engine(B, n=n, seed=2048)
 eng.init_weights(seed=7, scale=0.01)
 alpha = 0.25 * eng.num_feat / (8.0 * B)
