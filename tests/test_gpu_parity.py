@@ -364,6 +364,7 @@ def test_lane_sort_is_invisible(n, lag, monkeypatch):
     lag 0: sorted in line."""
     monkeypatch.setenv('G2048_SORT_MIN', '1')
     monkeypatch.setenv('G2048_SORT_LAG', str(lag))
+    monkeypatch.setenv('G2048_PLAY_HOT_MIN', '1' if lag else str(1 << 30))      # with and without the LDS hot set (the kernel that re-orders has both forms)
     B = 3000
     eng = Engine(B, n=n, seed=600 + n)
     eng.set_auto_reset(False)
