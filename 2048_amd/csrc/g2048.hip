@@ -502,9 +502,10 @@ constexpr int PLAY_HOT_WG = 512;        // one workgroup per CU shares the copy 
 // (tools/hot_coverage.py).  So "hot" is one compare on a number the gather computes anyway and t is the LDS index.
 template <int TPB>
 __device__ __forceinline__ void load_hot_set(float* hot, const float* __restrict__ w) {
-    for (uint32_t j = threadIdx.x; j < HOT_SLOTS; j += TPB) {
+    static_assert(HOT_PER_FEATURE % 4u == 0u, "the copy moves 16 bytes per thread and turn");
+    for (uint32_t j = 4u * threadIdx.x; j < HOT_SLOTS; j += 4u * TPB) {
         const uint32_t f = j / HOT_PER_FEATURE, t = j - f * HOT_PER_FEATURE;
-        hot[j] = w[f * 65536u + t];
+        *reinterpret_cast<float4*>(hot + j) = *reinterpret_cast<const float4*>(w + f * 65536u + t);
     }
     __syncthreads();
 }
@@ -827,7 +828,7 @@ __global__ __launch_bounds__(TPB, G2048_PLAY_MIN_WAVES) void k_td_play(LaneSet i
     constexpr float F = (float)Shape<N>::F;
     const uint32_t* const perm = PERM ? perm_ : nullptr;       // (compile-time: a run-time test would put a wait behind every block's first load)
     __shared__ WgStats ws;
-    __shared__ float hot[HOT ? HOT_SLOTS : 1];
+    __shared__ __attribute__((aligned(16))) float hot[HOT ? HOT_SLOTS : 4];
     wg_stats_init(&ws);
     if constexpr (HOT) load_hot_set<TPB>(hot, w);
     if (blockIdx.x == 0 && threadIdx.x < PLAY_SEGS) {
