@@ -8,6 +8,9 @@ n, B = int(os.environ.get('N', 5)), 1 << 20
 eng = pkg.Engine(B, n=n, seed=2048)
 eng.init_weights(seed=7, scale=0.01)
 alpha = 0.25 * eng.num_feat / (8.0 * B)
+if os.environ.get('RULE', 'sum') == 'mean':
+    eng.set_update_rule(1)
+    alpha = 0.25
 eng.td_steps(alpha, int(os.environ.get("STEPS", 300)))
 for rep in range(int(os.environ.get("REPS", 2))):
     a, b = eng.td_steps_profiled(alpha, 10)
