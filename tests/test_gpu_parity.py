@@ -338,6 +338,7 @@ def test_td_hot_set_path_vs_oracle(n, B, monkeypatch):
     forced on at a small batch: mid-game boards mix hot and cold tuples, random boards of tiles 0..13 are almost all cold; every
     step is checked against the float64 oracle as everywhere else."""
     monkeypatch.setenv('G2048_PLAY_HOT_MIN', '1')
+    monkeypatch.setenv('G2048_PLAY_HOT', '2')                # (2: for n = 6 too, where it is off by default)
     eng = Engine(B, n=n, seed=900 + n)
     eng.set_auto_reset(False)
     eng.step_random(30)
@@ -365,6 +366,7 @@ def test_lane_sort_is_invisible(n, lag, monkeypatch):
     monkeypatch.setenv('G2048_SORT_MIN', '1')
     monkeypatch.setenv('G2048_SORT_LAG', str(lag))
     monkeypatch.setenv('G2048_PLAY_HOT_MIN', '1' if lag else str(1 << 30))      # with and without the LDS hot set (the kernel that re-orders has both forms)
+    monkeypatch.setenv('G2048_PLAY_HOT', '2')
     B = 3000
     eng = Engine(B, n=n, seed=600 + n)
     eng.set_auto_reset(False)
