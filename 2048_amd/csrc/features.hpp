@@ -52,6 +52,27 @@ G2048_HD uint32_t bit_transpose16(uint32_t v) {       // the low 16 bits as a 4 
 }
 G2048_HD uint32_t table_place(uint32_t slot) { return bit_transpose16(slot); }
 
+// ---- the order of the cross orbit's accumulation table (five cells, 20 index bits): all five cells' bits transposed,
+// [bit 3 of cells 0..4 | bit 2 .. | bit 1 .. | bit 0 ..].  The table is cut into chunks by its TOP bits, which are then the
+// cells' high bits: nearly all of a step's adds fall into the first two of its 64 chunks instead of into ten to twenty,
+// and a chunk costs a scan of all records.  (The member tables in memory keep table_place: a gather wants the low bits of
+// FOUR cells inside a line, a chunk wants the high bits of ALL cells on top.)
+G2048_HD uint32_t cross_order(uint32_t k) {
+    const uint32_t t = bit_transpose16(k & 0xFFFFu), c4 = k >> 16;          // t: four planes of four bits; c4: the fifth cell
+    uint32_t out = 0;
+    for (uint32_t b = 0; b < 4u; ++b) out |= (((t >> (4u * b)) & 15u) | (((c4 >> b) & 1u) << 4)) << (5u * b);
+    return out;
+}
+G2048_HD uint32_t cross_unorder(uint32_t o) {
+    uint32_t t = 0, c4 = 0;
+    for (uint32_t b = 0; b < 4u; ++b) {
+        const uint32_t plane = (o >> (5u * b)) & 31u;
+        t |= (plane & 15u) << (4u * b);
+        c4 |= (plane >> 4) << b;
+    }
+    return (c4 << 16) | bit_transpose16(t);
+}
+
 G2048_HD uint32_t pack16(uint32_t w) {      // bytes b0..b3 (cells 0..3 of a line) -> b0<<12|b1<<8|b2<<4|b3
     return ((w & 0xFu) << 12) | ((w >> 8 & 0xFu) << 8) | ((w >> 16 & 0xFu) << 4) | (w >> 24 & 0xFu);
 }

@@ -721,7 +721,10 @@ __device__ __forceinline__ void store_orbit_indices(uint8_t* base, uint32_t B, u
         feature_slots<N>(d4_image(p, g), s);            // g is constant after unrolling; what no orbit visits is dead code
 #pragma unroll
         for (int v = 0; v < (N == 4 ? 5 : 6); ++v)
-            if ((COSET_MASK[v] >> g) & 1u) idx[v][coset_rank(COSET_MASK[v], g)] = s[ORBIT_REPS[v]] - feature_offset(N, ORBIT_REPS[v]);
+            if ((COSET_MASK[v] >> g) & 1u) {
+                const uint32_t rel = s[ORBIT_REPS[v]] - feature_offset(N, ORBIT_REPS[v]);
+                idx[v][coset_rank(COSET_MASK[v], g)] = v == 5 ? cross_order(rel) : rel;        // (the cross orbit's table: features.hpp)
+            }
     }
     const OrbitIdx o = orbit_idx(base, B);
 #pragma unroll
@@ -1217,7 +1220,7 @@ template <> struct OwnVariants<2> { static constexpr int COUNT = 1; static const
 template <> struct OwnVariants<3> { static constexpr int COUNT = 13; static constexpr int f0(int v) { return 4 * v; } static constexpr int fc(int) { return 4; } };   // 4 x 4096 fixed-point slots = 128 KiB
 
 #ifndef G2048_FIXED_VARIANTS
-#define G2048_FIXED_VARIANTS 5      // (6 = the cross orbit too: twice the chunks to scan, measured 0.20 -> 0.245 ms)
+#define G2048_FIXED_VARIANTS 6      // (5 = the cross orbit in fp32: half as many, twice as large chunks, but ds_add_f32 is 12x slower than ds_add_u64)
 #endif
 // which variants sum in 64-bit fixed point: the five four-cell orbits of n >= 4, and every feature group of n = 2, 3
 // (n = 3: 2.25 -> 0.36 ms per update, n = 2: 1.07 -> 0.24 ms)
@@ -1264,7 +1267,9 @@ __device__ __forceinline__ void own_accum(const Packed& p, float dw, bool valid,
         feature_slots<N>(d4_image(p, g), s);         // g is a constant after unrolling; unused slots are dead code
 #pragma unroll
         for (int f = F0; f < F0 + FC; ++f) {
-            const uint32_t local = s[f] - sl.tlo;
+            const bool cross = N >= 5 && f >= 17 && f < 21;                 // the cross orbit's table is in cross_order
+            const uint32_t orel = cross ? cross_order(s[f] - sl.orb_tlo) : 0u;
+            const uint32_t local = cross ? orel - (sl.tlo - sl.orb_tlo) : s[f] - sl.tlo;
             const bool hit = valid && local < sl.size;
             if (hit) {
                 if (FIXED)
@@ -1274,7 +1279,7 @@ __device__ __forceinline__ void own_accum(const Packed& p, float dw, bool valid,
             }
             nhit += hit ? 1u : 0u;
             if (FB && valid && !hit) {
-                const uint32_t rel = s[f] - sl.orb_tlo, ch = rel >> sl.cshift;
+                const uint32_t rel = cross ? orel : s[f] - sl.orb_tlo, ch = rel >> sl.cshift;
                 if ((sl.fb_mask >> ch) & 1u) {
                     __hip_atomic_fetch_add(&D[sl.orb_dlo + rel], dw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (Dc) __hip_atomic_fetch_add(&Dc[sl.orb_dlo + rel], 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1532,7 +1537,8 @@ __global__ __launch_bounds__(WG) void k_apply_orbits(float* w, float* dacc, floa
     for (uint32_t j = 1; j < MAX_ORBITS; ++j)
         if (j < t.count && K >= t.o[j].base) o = j;
     const OrbitInfo& oi = t.o[o];
-    const uint32_t k = K - oi.base;
+    const bool cross = oi.radix == 16u && oi.digits == 5u;              // its table is in cross_order
+    const uint32_t k = cross ? cross_unorder(K - oi.base) : K - oi.base;
     float v;
     uint32_t k2 = k;        // f_6 orbit with a stabiliser {e, sigma}: the thread of the smaller of k, sigma(k) serves both
     if (K >= owned) {
@@ -1549,7 +1555,10 @@ __global__ __launch_bounds__(WG) void k_apply_orbits(float* w, float* dacc, floa
         D[K] = 0.0f;
     } else {            // symmetrise over the stabiliser
         v = cur[K];
-        for (uint32_t s = 1; s < oi.nstab; ++s) v += cur[oi.base + permute_digits(k, oi.sperm[s], oi.digits, oi.radix)];
+        for (uint32_t s = 1; s < oi.nstab; ++s) {
+            const uint32_t j = permute_digits(k, oi.sperm[s], oi.digits, oi.radix);
+            v += cur[oi.base + (cross ? cross_order(j) : j)];
+        }
         if (v == 0.0f) return;
     }
     add_to_members(w, dacc, oi, k, v);
@@ -1572,7 +1581,8 @@ __global__ __launch_bounds__(WG) void k_apply_orbits_mean(float* w, float* dacc,
     for (uint32_t j = 1; j < MAX_ORBITS; ++j)
         if (j < t.count && K >= t.o[j].base) o = j;
     const OrbitInfo& oi = t.o[o];
-    const uint32_t k = K - oi.base;
+    const bool cross = oi.radix == 16u && oi.digits == 5u;
+    const uint32_t k = cross ? cross_unorder(K - oi.base) : K - oi.base;
     float cnt, sum;
     uint32_t k2 = k;
     if (K >= owned) {
@@ -1595,7 +1605,8 @@ __global__ __launch_bounds__(WG) void k_apply_orbits_mean(float* w, float* dacc,
         cnt = ccur[K];
         sum = scur[K];
         for (uint32_t s = 1; s < oi.nstab; ++s) {
-            const uint32_t j = oi.base + permute_digits(k, oi.sperm[s], oi.digits, oi.radix);
+            const uint32_t pj = permute_digits(k, oi.sperm[s], oi.digits, oi.radix);
+            const uint32_t j = oi.base + (cross ? cross_order(pj) : pj);
             cnt += ccur[j];
             sum += scur[j];
         }

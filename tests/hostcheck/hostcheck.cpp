@@ -128,4 +128,10 @@ int hc_memory_slots(int n, const uint8_t* boards, int64_t count, int32_t* out) {
     }
     return 0;
 }
+void hc_cross_order(int64_t count, uint32_t* fwd, uint32_t* back) {       // cross_order(k) and cross_unorder(k) for k = 0 .. count-1
+    for (int64_t k = 0; k < count; ++k) {
+        fwd[k] = cross_order((uint32_t)k);
+        back[k] = cross_unorder((uint32_t)k);
+    }
+}
 }

@@ -228,3 +228,20 @@ def test_table_places_are_bijections_and_memory_slots_agree(hc, golden):
         hi = np.append(np.asarray(offs, np.int64)[1:], total)[None, :]
         m = mem.astype(np.int64)
         assert (m >= lo).all() and (m < hi).all()
+
+
+def test_cross_order_is_a_bijection_with_the_cells_high_bits_on_top(hc):
+    """The cross orbit's accumulation table is indexed by cross_order (features.hpp): a bijection of the 20-bit index, its
+    inverse cross_unorder, and bit 5 b + j of the result = bit b of cell j (so the top five bits are bit 3 of the cells)."""
+    n = 1 << 20
+    fwd, back = np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+    hc.hc_cross_order(ctypes.c_int64(n), ptr(fwd), ptr(back))
+    k = np.arange(n, dtype=np.uint32)
+    assert np.array_equal(np.sort(fwd), k)
+    assert np.array_equal(back[fwd], k) and np.array_equal(fwd[back], k)
+    cells = [(k >> (4 * j)) & 15 for j in range(5)]
+    want = np.zeros(n, np.uint32)
+    for b in range(4):
+        for j in range(5):
+            want |= ((cells[j] >> b) & 1).astype(np.uint32) << np.uint32(5 * b + j)
+    assert np.array_equal(fwd, want)
