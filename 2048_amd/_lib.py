@@ -95,6 +95,7 @@ SIGNATURES = {
     'g2048_comm_unique_id': (c_int, [_P]),
     'g2048_comm_init': (c_int, [_P, c_int, c_int, _P]),
     'g2048_comm_destroy': (c_int, [_P]),
+    'g2048_comm_info': (c_int, [_P, POINTER(c_int), POINTER(c_int)]),
     'g2048_allreduce_deltas': (c_int, [_P]),
     'g2048_allreduce_f64': (c_int, [_P, _P, c_int, c_int]),
 }

@@ -416,23 +416,8 @@ class QAgent:
             return None
         if self._sync is None:
             from . import parallel
-            eng, sync = self.engine, None
-            if self.comm == 'native':
-                import torch
-                ok = 1
-                try:
-                    sync = parallel.NativeSync(eng, self.rank, self.world, parallel.broadcast_id_torch(self._dist))
-                except Exception as e:                         # (every rank must agree before falling back)
-                    self.print(f'rank {self.rank}: native RCCL path unavailable ({e!r}); using torch.distributed')
-                    ok = 0
-                flag = torch.tensor([ok], dtype=torch.int32, device=f'cuda:{self.device}' if self._dist.get_backend() == 'nccl' else 'cpu')
-                self._dist.all_reduce(flag, op=self._dist.ReduceOp.MIN)
-                if int(flag.item()) == 0:
-                    if sync is not None:
-                        sync.close()
-                    sync = None
-            if sync is None:
-                sync = parallel.DeltaSync(eng, self._dist, rule=self.rule)
+            sync, _ = parallel.make_sync(self.engine, self._dist, self.rank, self.world, rule=self.rule, comm=self.comm,
+                                         log=self.print)
             sync.begin()
             self._sync = sync
         return self._sync

@@ -3863,6 +3863,8 @@ struct Rccl {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;          // optional: what the communicator itself reports
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
     std::string err;
 };
 Rccl* rccl() {
@@ -3880,6 +3882,8 @@ Rccl* rccl() {
     r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.lib, "ncclCommDestroy"));
     r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(dlsym(r.lib, "ncclAllReduce"));
     r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.lib, "ncclGetErrorString"));
+    r.CommCount = reinterpret_cast<decltype(r.CommCount)>(dlsym(r.lib, "ncclCommCount"));
+    r.CommUserRank = reinterpret_cast<decltype(r.CommUserRank)>(dlsym(r.lib, "ncclCommUserRank"));
     if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce || !r.GetErrorString) {
         r.err = "librccl lacks an expected symbol";
         r.lib = nullptr;
@@ -3921,6 +3925,24 @@ int g2048_comm_init(g2048_ctx* c, int rank, int nranks, const uint8_t* id) {
     c->comm = comm;
     c->comm_rank = rank;
     c->comm_ranks = nranks;
+    return G2048_OK;
+}
+
+// What the communicator itself says (ncclCommCount / ncclCommUserRank), not what g2048_comm_init was told: the record of
+// a multi-GPU run can then show that RCCL saw all N ranks.  No communicator: rank 0 of 1, G2048_OK.
+int g2048_comm_info(g2048_ctx* c, int* rank, int* nranks) {
+    if (!c || !rank || !nranks) return c ? fail(c, G2048_ERR_ARG, "null output") : G2048_ERR_ARG;
+    *rank = 0;
+    *nranks = 1;
+    if (!c->comm) return G2048_OK;
+    Rccl* r = rccl();
+    *rank = c->comm_rank;
+    *nranks = c->comm_ranks;
+    if (r->CommCount && r->CommUserRank) {
+        ncclResult_t e = r->CommCount((ncclComm_t)c->comm, nranks);
+        if (e == ncclSuccess) e = r->CommUserRank((ncclComm_t)c->comm, rank);
+        if (e != ncclSuccess) return rccl_fail(c, "ncclCommCount", e);
+    }
     return G2048_OK;
 }
 

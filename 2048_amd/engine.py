@@ -300,6 +300,12 @@ class Engine:
     def comm_destroy(self):
         self._c(self.lib.g2048_comm_destroy(self.ctx))
 
+    def comm_info(self):
+        """(rank, nranks) as the RCCL communicator itself reports them; (0, 1) without one."""
+        r, n = ctypes.c_int(), ctypes.c_int()
+        self._c(self.lib.g2048_comm_info(self.ctx, ctypes.byref(r), ctypes.byref(n)))
+        return r.value, n.value
+
     def allreduce_deltas(self):
         """End of an epoch on the context's stream: RCCL sum all-reduce of the accumulated delta, W = W0 + result."""
         self._c(self.lib.g2048_allreduce_deltas(self.ctx))

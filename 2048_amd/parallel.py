@@ -106,13 +106,38 @@ class DeltaSync:
 
 class NativeSync:
     """The C ABI's own RCCL path: g2048_comm_init once (collective), then g2048_allreduce_deltas per epoch, queued on
-    the engine's stream.  `exchange_id(id_or_None) -> id` carries rank 0's 128-byte unique id to every rank (any
-    out-of-band channel: torch.distributed broadcast, a TCPStore, a file)."""
+    the engine's stream.
 
-    def __init__(self, engine, rank, world, exchange_id):
-        uid = engine.comm_unique_id() if rank == 0 else None
-        uid = exchange_id(uid)
-        engine.comm_init(rank, world, uid)
+    Setting it up is itself a little protocol, and every rank walks through ALL of its collective steps whatever
+    happens locally, so that a failure on one rank (librccl missing, ncclCommInitRank refusing) can never leave the
+    ranks in different collectives (round 2's version raised on rank 0 before the id broadcast the other ranks
+    were already waiting in):
+      1. every rank probes the library (g2048_comm_unique_id: loads librccl, creates an id; only rank 0's is used);
+      2. `exchange_id(id_or_None) -> id` carries rank 0's 128-byte id (or None) to every rank — any out-of-band
+         channel: torch.distributed broadcast, a TCPStore, a file;
+      3. `agree(ok) -> bool` (logical AND over the ranks): does everyone have a library and an id?  If not, ALL raise;
+      4. g2048_comm_init (ncclCommInitRank, collective), then agree() again: if any rank failed, those that succeeded
+         destroy their communicator and ALL raise.
+    A caller that catches the exception therefore falls back on every rank or on none."""
+
+    def __init__(self, engine, rank, world, exchange_id, agree=None):
+        agree = agree or (lambda ok: ok)
+        err = None
+        try:
+            uid = engine.comm_unique_id()
+        except Exception as e:                 # no librccl here: still take part in steps 2 and 3
+            uid, err = None, e
+        uid = exchange_id(uid if rank == 0 else None)
+        if not agree(err is None and uid is not None):
+            raise RuntimeError(f'native RCCL path unavailable on at least one rank (rank {rank}: {err!r})')
+        try:
+            engine.comm_init(rank, world, uid)
+        except Exception as e:
+            err = e
+        if not agree(err is None):
+            if err is None:
+                engine.comm_destroy()
+            raise RuntimeError(f'g2048_comm_init failed on at least one rank (rank {rank}: {err!r})')
         self.e = engine
         self.reduces = 0
 
@@ -122,6 +147,10 @@ class NativeSync:
     def all_reduce(self):
         self.e.allreduce_deltas()                          # the update rule is the context's (g2048_set_update_rule)
         self.reduces += 1
+
+    def info(self):
+        """(rank, nranks) as the communicator reports them (ncclCommUserRank / ncclCommCount)."""
+        return self.e.comm_info()
 
     def close(self):
         self.e.comm_destroy()
@@ -134,6 +163,28 @@ def broadcast_id_torch(dist, group=None):
         dist.broadcast_object_list(box, src=0, group=group)
         return box[0]
     return exchange
+
+
+def agree_torch(dist, group=None):
+    """agree for NativeSync: logical AND of a host flag over the ranks (object collective: works on any backend
+    without a device tensor)."""
+    def agree(ok):
+        flags = [None] * dist.get_world_size(group)
+        dist.all_gather_object(flags, bool(ok), group=group)
+        return all(flags)
+    return agree
+
+
+def make_sync(engine, dist, rank, world, rule='sum', comm='native', log=None, group=None):
+    """The per-epoch exchange for one rank of a torch.distributed job: the native RCCL path if every rank can set it
+    up, otherwise (all ranks together) torch.distributed's all_reduce.  Returns (sync, kind)."""
+    if comm == 'native':
+        try:
+            return NativeSync(engine, rank, world, broadcast_id_torch(dist, group), agree_torch(dist, group)), 'native'
+        except Exception as e:
+            if log:
+                log(f'rank {rank}: {e}; using torch.distributed all_reduce')
+    return DeltaSync(engine, dist, group=group, rule=rule), 'torch'
 
 
 def reduce_stats(stats, dist, device='cpu', group=None):

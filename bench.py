@@ -146,26 +146,114 @@ def emit(out):
     os.write(_RESULT_FD if _RESULT_FD is not None else 1, line)
 
 
+def _tail(path, lines=40):
+    try:
+        with open(path, 'rb') as f:
+            return b''.join(f.readlines()[-lines:]).decode(errors='replace')
+    except OSError:
+        return ''
+
+
 def self_launch(args):
     """--gpus N without a launcher: start the N rank processes (fresh interpreters, so no GPU state is inherited — this
-    parent never imports torch or the HIP library), relay rank 0's stdout, fail if any rank fails."""
-    s = socket.socket()
-    s.bind(('127.0.0.1', 0))
-    port = s.getsockname()[1]
-    s.close()
-    procs = []
-    for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
-                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
-    out, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out.decode())
+    parent never imports torch or the HIP library and nothing is re-exec'ed), relay rank 0's stdout.
+
+    The parent watches ALL ranks: the first one that exits non-zero ends the run — the others are terminated (a rank whose
+    peer died would otherwise sit in a collective until the backend's own timeout), that rank's stderr tail is printed and
+    the parent exits non-zero; --deadline bounds the whole run the same way.  Every rank's stderr goes to a file under a
+    temporary directory and is copied to the parent's stderr at the end."""
+    import shutil
+    import tempfile
+    import ctypes
+    tmp = tempfile.mkdtemp(prefix='g2048_bench_')
+    t_start = time.monotonic()
+    libc = ctypes.CDLL(None)
+
+    def die_with_parent():
+        libc.prctl(1, 15)                          # PR_SET_PDEATHSIG, SIGTERM
+
+    def launch():
+        s = socket.socket()
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+        s.close()
+        procs, files = [], []
+        for r in range(args.gpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                       MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+            err = open(os.path.join(tmp, f'rank{r}.err'), 'wb')
+            out = open(os.path.join(tmp, f'rank{r}.out'), 'wb')
+            files += [err, out]
+            # same process group as the parent (a kill of the group takes the ranks along), and SIGTERM if the parent dies
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stdout=out, stderr=err, preexec_fn=die_with_parent))
+        return procs, files
+
+    def stop(procs):
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t_end = time.monotonic() + 5.0
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_end - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+
+    verdict, attempt = None, 0
+    while verdict is None:
+        attempt += 1
+        procs, files = launch()
+        t_launch = time.monotonic()
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [r for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                stop(procs)
+                r = bad[0]
+                tail = _tail(os.path.join(tmp, f'rank{r}.err'))
+                # the rendezvous port was picked by bind + close: another process may have taken it in between
+                if attempt == 1 and time.monotonic() - t_launch < 30 and ('EADDRINUSE' in tail or 'ddress already in use' in tail):
+                    print(f'[bench] rendezvous port was taken, launching once more', file=sys.stderr)
+                    break
+                verdict = f'rank {r} exited with code {codes[r]} (the other ranks were terminated); its stderr tail:\n{tail}'
+                break
+            if all(c == 0 for c in codes):
+                verdict = ''
+                break
+            if time.monotonic() - t_start > args.deadline:
+                stop(procs)
+                alive = [r for r, c in enumerate(codes) if c is None]
+                verdict = (f'--deadline {args.deadline:.0f} s passed with ranks {alive} still running (terminated); stderr tails:\n'
+                           + '\n'.join(f'--- rank {r}\n' + _tail(os.path.join(tmp, f'rank{r}.err'), 15) for r in alive))
+                break
+            time.sleep(0.05)
+        for f in files:
+            f.close()
+    for r in range(args.gpus):                     # the ranks' diagnostics, in rank order
+        sys.stderr.write(_tail(os.path.join(tmp, f'rank{r}.err'), 200 if verdict else 50))
+    line = _tail(os.path.join(tmp, 'rank0.out'), 5)
+    shutil.rmtree(tmp, ignore_errors=True)
+    if verdict:
+        raise SystemExit('[bench] FAILED: ' + verdict)
+    sys.stdout.write(line)
     sys.stdout.flush()
-    bad = [c for c in codes if c != 0]
-    if bad:
-        raise SystemExit(f'rank exit codes {codes}')
+
+
+def fault_inject(spec, rank, where):
+    """Test hook (tests/test_cpu_host.py, tests/test_gpu_multi.py): --fault-inject 'exit@1:init,hang@0:init' makes rank 1
+    exit with code 3 and rank 0 sleep at the named point, so that the launcher's failure handling can be exercised."""
+    for item in filter(None, (spec or '').split(',')):
+        what, _, rest = item.partition('@')
+        r, _, at = rest.partition(':')
+        if int(r) == rank and (at or 'init') == where:
+            if what == 'exit':
+                print(f'[bench] rank {rank}: injected failure at {where}', file=sys.stderr)
+                sys.stderr.flush()
+                os._exit(3)
+            if what == 'hang':
+                time.sleep(3600)
 
 
 def main():
@@ -194,6 +282,9 @@ def main():
     ap.add_argument('--comm', default='native', choices=['native', 'torch'],
                     help='delta all-reduce: native = g2048_allreduce_deltas (RCCL on the engine stream; falls back to torch if it '
                          'cannot be set up), torch = torch.distributed all_reduce')
+    ap.add_argument('--deadline', type=float, default=900.0,
+                    help='self-launched N > 1 runs: seconds after which the parent terminates every rank and fails')
+    ap.add_argument('--fault-inject', default='', help=argparse.SUPPRESS)
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend for control traffic (nccl = RCCL; gloo to rehearse on one GPU)')
     args = ap.parse_args()
 
@@ -217,13 +308,18 @@ def main():
             os.environ.setdefault('MASTER_PORT', '29517')
             os.environ.setdefault('RANK', '0')
             os.environ.setdefault('WORLD_SIZE', '1')
+        import datetime
+        limit = datetime.timedelta(seconds=max(60.0, min(args.deadline, 600.0)))    # a lost peer fails the collective, not the day
+        fault_inject(args.fault_inject, rank, 'start')
         if args.backend == 'nccl':
             torch.cuda.set_device(local_rank)
-            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))   # RCCL over xGMI
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank), timeout=limit)   # RCCL over xGMI
         else:
-            local_rank = local_rank % torch.cuda.device_count()
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group(args.backend)
+            if torch.cuda.device_count():
+                local_rank = local_rank % torch.cuda.device_count()
+                torch.cuda.set_device(local_rank)
+            dist.init_process_group(args.backend, timeout=limit)
+        fault_inject(args.fault_inject, rank, 'init')
 
     # torch first: it must initialise its HIP runtime before lib2048_hip.so brings up its own
     copy_gbps = measured_copy_gbps(local_rank) if args.workload == 'td' else None
@@ -242,24 +338,11 @@ def main():
 
     sync, comm_kind = None, None
     if dist:
-        if args.comm == 'native':
-            ok = 1
-            try:
-                sync = par.NativeSync(eng, rank, world, par.broadcast_id_torch(dist))
-                comm_kind = 'native g2048_allreduce_deltas (ncclAllReduce on the engine stream)'
-            except Exception as e:          # e.g. librccl absent: every rank must agree before falling back
-                print(f'[bench] rank {rank}: native RCCL path unavailable ({e!r})', file=sys.stderr)
-                ok = 0
-            import torch
-            flag = torch.tensor([ok], dtype=torch.int32, device='cuda' if args.backend == 'nccl' else 'cpu')
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 0:
-                if sync is not None:
-                    sync.close()
-                sync = None
-        if sync is None:
-            sync = par.DeltaSync(eng, dist, rule=args.rule)
-            comm_kind = f'torch.distributed all_reduce ({args.backend})'
+        sync, kind = par.make_sync(eng, dist, rank, world, rule=args.rule, comm=args.comm,
+                                   log=lambda m: print(f'[bench] {m}', file=sys.stderr))
+        comm_kind = ('native g2048_allreduce_deltas (ncclAllReduce on the engine stream)' if kind == 'native'
+                     else f'torch.distributed all_reduce ({args.backend})')
+    fault_inject(args.fault_inject, rank, 'comm')
 
     def run(steps):
         par.run_epochs(eng, sync, alpha, steps, args.epoch)
@@ -283,6 +366,7 @@ def main():
         sync.begin()
     run(args.condition)                                    # input conditioning: untimed, not part of --warmup
     run(W)
+    fault_inject(args.fault_inject, rank, 'run')
     times, ev_times = [], []
     for _ in range(max(1, args.repeats)):
         barrier()
@@ -337,6 +421,27 @@ def main():
     if roofline['frac'] > 1.0 or roofline['k_td_play']['frac'] > 1.0:      # cannot happen for bytes a kernel really moves
         roofline['invalid'] = 'fraction above 1: bookkeeping error'
 
+    comm = None
+    if sync:
+        # the exchange on its own: barrier, one all-reduce of the epoch's delta + its apply pass, device drained; MAX over ranks
+        xs = []
+        for _ in range(3):
+            barrier()
+            t0 = time.perf_counter()
+            sync.all_reduce()
+            eng.sync()
+            xs.append(max_over_ranks(time.perf_counter() - t0) * 1e3)
+        payload = eng.slots * 4 * (2 if args.rule == 'mean' else 1)
+        seen = sync.info() if isinstance(sync, par.NativeSync) else (dist.get_rank(), dist.get_world_size())
+        link = 153e9                                       # one xGMI link, MI355X_MICROARCH.md
+        comm = {'kind': comm_kind, 'rank_seen': seen[0], 'nranks_seen': seen[1], 'nranks_expected': world,
+                'payload_bytes': payload, 'epoch_steps': args.epoch, 'exchanges_per_timed_region': -(-K // args.epoch),
+                'allreduce_plus_apply_ms': statistics.median(xs), 'allreduce_plus_apply_ms_repeats': xs,
+                'predicted_allreduce_ms': {'ring_one_link': 2 * (world - 1) / world * payload / link * 1e3,
+                                           'all_links_direct': (2 * payload / world / link * 1e3) if world > 1 else 0.0}}
+        if seen[1] != world:
+            raise SystemExit(f'[bench] the communicator reports {seen[1]} ranks, expected {world}')
+
     mean_line = None
     if world == 1 and not dist and args.rule == 'sum' and not args.no_mean_line:
         # the rule the product trains with (QAgent(batch > 1) -> g2048_set_update_rule(1)), same lanes, alpha unscaled
@@ -375,6 +480,8 @@ def main():
         }
         if mean_line:
             out['mean_rule'] = mean_line
+        if comm:
+            out['comm'] = comm
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(n, args.cpu_seconds)
         emit(out)

@@ -202,6 +202,9 @@ int g2048_stats_reset(g2048_ctx* ctx);
 int g2048_comm_unique_id(uint8_t* id /* [G2048_COMM_ID_BYTES] */);
 int g2048_comm_init(g2048_ctx* ctx, int rank, int nranks, const uint8_t* id /* [G2048_COMM_ID_BYTES] */);
 int g2048_comm_destroy(g2048_ctx* ctx);
+/* what the communicator itself reports (ncclCommUserRank / ncclCommCount) — rank 0 of 1 without a communicator; lets the
+ * record of a multi-GPU run prove how many ranks RCCL saw */
+int g2048_comm_info(g2048_ctx* ctx, int* rank, int* nranks);
 int g2048_allreduce_deltas(g2048_ctx* ctx);
 /* sum (op_max = 0) or maximum (1) of `count` host doubles over the ranks, in place: episode statistics, timings */
 int g2048_allreduce_f64(g2048_ctx* ctx, double* values, int count, int op_max);

@@ -101,3 +101,29 @@ def test_rng_spec_scalar_and_vector_agree():
         assert [int(v) for v in u] == [l.next() for l in lanes]
     r10, k = rng.spawn_draw_np(u, np.full(8, 7))
     assert [(int(a), int(b)) for a, b in zip(r10, k)] == [rng.spawn_draw(int(v), 7) for v in u]
+
+
+# ---- bench.py --gpus N as its own launcher: a dead or stuck rank must end the run at once.
+# gloo ranks on the CPU; the injected faults sit before anything would touch a GPU.
+def _bench(*extra, timeout=120):
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--backend', 'gloo', *extra],
+                       capture_output=True, text=True, timeout=timeout)
+    return r, time.monotonic() - t0
+
+
+def test_bench_launcher_fails_fast_when_a_rank_dies():
+    r, dt = _bench('--fault-inject', 'exit@1:init,hang@0:init')
+    assert r.returncode != 0 and dt < 60
+    assert 'rank 1 exited with code 3' in r.stderr and 'injected failure' in r.stderr
+    assert r.stdout.strip() == ''                                # no result line from a failed run
+
+
+def test_bench_launcher_deadline():
+    r, dt = _bench('--deadline', '8', '--fault-inject', 'hang@0:init,hang@1:init')
+    assert r.returncode != 0 and dt < 60
+    assert '--deadline 8 s passed' in r.stderr

@@ -156,3 +156,66 @@ def test_shard_lanes_cover_everything():
             assert spans[0][0] == 0 and sum(c for _, c in spans) == total
             for (a, ca), (b, _) in zip(spans, spans[1:]):
                 assert a + ca == b
+
+
+# ---- NativeSync's set-up protocol: a failure on ONE rank must leave every rank in the same place (rank 0
+# raised before the id broadcast the other ranks were already waiting in).  The engine is a stand-in here (no GPU); the
+# protocol under test is host code.
+class FakeEngine:
+    def __init__(self, rank, fail):
+        self.rank, self.fail, self.inited, self.destroyed = rank, fail, False, False
+
+    def comm_unique_id(self):
+        if self.fail == ('load', self.rank):
+            raise OSError('librccl not found (injected)')
+        return bytes([self.rank + 1]) * 128
+
+    def comm_init(self, rank, world, uid):
+        assert uid == bytes([1]) * 128, 'rank 0\'s id reaches every rank'
+        if self.fail == ('init', self.rank):
+            raise RuntimeError('ncclCommInitRank refused (injected)')
+        self.inited = True
+
+    def comm_destroy(self):
+        self.destroyed = True
+
+    def comm_info(self):
+        return self.rank, 2
+
+
+def native_worker(rank, world, port, fail, out_dir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    import datetime
+    dist.init_process_group('gloo', rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    eng = FakeEngine(rank, fail)
+    raised = False
+    try:
+        parallel.NativeSync(eng, rank, world, parallel.broadcast_id_torch(dist), parallel.agree_torch(dist))
+    except RuntimeError:
+        raised = True
+    # whatever happened, the ranks are still in step: the next collective pairs up and gives the right answer
+    t = torch.tensor([float(rank + 1)])
+    dist.all_reduce(t)
+    assert t.item() == 3.0
+    with open(os.path.join(out_dir, f'r{rank}.txt'), 'w') as f:
+        f.write(f'{int(raised)} {int(eng.inited)} {int(eng.destroyed)}')
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('fail', [None, ('load', 0), ('load', 1), ('init', 0), ('init', 1)])
+def test_native_sync_setup_fails_on_all_ranks_or_none(tmp_path, fail):
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(native_worker, args=(2, port, fail, str(tmp_path)), nprocs=2, join=True)
+    res = [tuple(int(x) for x in open(tmp_path / f'r{r}.txt').read().split()) for r in range(2)]
+    if fail is None:
+        assert res == [(0, 1, 0), (0, 1, 0)]
+    else:
+        assert res[0][0] == 1 and res[1][0] == 1                 # both ranks raised
+        if fail[0] == 'load':
+            assert not res[0][1] and not res[1][1]               # nobody entered ncclCommInitRank
+        else:
+            ok_rank = 1 - fail[1]
+            assert res[ok_rank] == (1, 1, 1)                     # the rank that got a communicator gave it back
