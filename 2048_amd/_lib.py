@@ -72,6 +72,7 @@ SIGNATURES = {
     'g2048_update': (c_int, [_P, _P, _P, c_int64]),
     'g2048_td_steps': (c_int, [_P, c_float, c_uint32]),
     'g2048_set_lane_sort': (c_int, [_P, c_uint32]),
+    'g2048_debug_lane_order': (c_int, [_P, _P, _P]),
     'g2048_set_update_mode': (c_int, [_P, c_int]),
     'g2048_set_update_rule': (c_int, [_P, c_int]),
     'g2048_get_last_move': (c_int, [_P, _P]),

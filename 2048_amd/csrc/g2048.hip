@@ -35,10 +35,6 @@
 
 using namespace g2048;
 
-// lane_sort.hip: device radix sort of (key, lane position) pairs; temp == nullptr asks for the scratch size
-extern "C" int g2048_lane_sort_pairs(void* temp, size_t* temp_bytes, const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* vals_in,
-                                     uint32_t* vals_out, uint32_t n, int begin_bit, int end_bit, hipStream_t stream);
-
 namespace {
 
 constexpr int WG = 256;
@@ -1904,43 +1900,122 @@ __global__ __launch_bounds__(WG) void k_hex_apply(float* w, float* dacc, float* 
 // ------------------------------------------------------------------------------------------------ lane order (LaneSort)
 // k_td_play is bound by L1 misses of its table gathers: a CU's 32 KB L1 sees ~4 000 unrelated boards per launch.  Which
 // cache lines a board's COLD tuples touch is decided by where its big tiles sit (the small ones come and go every move),
-// so lanes with the same big-tile pattern use the same lines.  Every few steps the lanes are therefore re-ordered by
-// that pattern: a 48-bit key per lane (3 bits per cell: how far the tile is above SORT_TILE, else 0), one radix sort,
-// and the next k_td_play reads its lanes through the permutation and writes them back in the new order (no separate
-// copy pass).  The host never sees the order: lane_id travels with the lane and every lane-addressed entry point of the
-// ABI first restores the identity order (k_restore_order).
-constexpr uint32_t SORT_TILE = 5;
-#ifndef G2048_SORT_CELL_BITS
-#define G2048_SORT_CELL_BITS 3
-#endif
-#ifndef G2048_SORT_STEP
-#define G2048_SORT_STEP 1
-#endif
-constexpr int SORT_CELL_BITS = G2048_SORT_CELL_BITS;       // key bits per cell
-constexpr uint32_t SORT_STEP = G2048_SORT_STEP;            // tiles per key value above SORT_TILE
+// so lanes with the same big-tile pattern use the same lines.  Every few steps the lanes are therefore re-ordered by that
+// pattern, and the next k_td_play reads its lanes through the permutation and writes them back in the new order (no
+// separate copy pass).  The host never sees the order: lane_id travels with the lane and every lane-addressed entry point
+// of the ABI first restores the identity order (k_restore_order).
+//
+// The re-order is a counting sort on a 16-bit key — one bit per cell: "the tile is above SORT_TILE" — in three launches
+// (round 2 called rocPRIM's radix sort on a 48-bit key: 21 launches, 0.19 ms):
+//   k_sort_count   one 1 024-thread workgroup per 4 096 lanes.  All 65 536 counters of the tile live in LDS (16 bits each,
+//                  two per word): a lane's ds_add_rtn gives its rank among the tile's lanes with the same key; the first
+//                  lane of every key present then reserves the tile's share of the key's bucket with ONE global atomic
+//                  (<= 256 atomics per key and sort, however skewed the keys) and passes the reserved offset on to the
+//                  others through LDS;
+//   k_sort_scan    exclusive scan of the 65 536 bucket sizes (one workgroup), counters cleared for the next sort;
+//   k_sort_scatter perm[bucket start + offset] = position.
+// Inside a bucket the order is that of the tiles' reservations, i.e. not reproducible from run to run; nothing observable
+// depends on it (the lanes' games do not, the fixed-point sums of the update do not).
+constexpr uint32_t SORT_TILE = 5;               // default threshold (G2048_SORT_TILE): key bit set for tiles above 2^5
+constexpr uint32_t SORT_KEYS = 65536, SORT_TPB = 1024, SORT_PER_THREAD = 4, SORT_LANES_PER_WG = SORT_TPB * SORT_PER_THREAD;
+
+// one bit per cell, row 0 in the top nibble: tile > thr (tiles are < 128, so the carry into bit 7 of each byte lane is the test)
+__device__ __forceinline__ uint32_t sort_key(const Board& b, uint32_t thr) {
+    const uint32_t bias = (0x7Fu - thr) * 0x01010101u;
+    uint32_t key = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const uint32_t m = ((b.r[r] + bias) & 0x80808080u) >> 7;          // bits 0, 8, 16, 24
+        key = (key << 4) | ((m | m >> 7 | m >> 14 | m >> 21) & 0xFu);
+    }
+    return key;
+}
 
 __global__ __launch_bounds__(WG) void k_iota(uint32_t* v, uint32_t n) {
     uint32_t i = blockIdx.x * WG + threadIdx.x;
     if (i < n) v[i] = i;
 }
 
-__global__ __launch_bounds__(WG) void k_sort_keys(const uint4* boards, uint32_t B, uint64_t* keys) {
-    uint32_t i = blockIdx.x * WG + threadIdx.x;
-    if (i >= B) return;
-    const Board b = ld_board(boards, i);
-    uint64_t key = 0;           // SORT_CELL_BITS per cell, row-major: 0 for a tile <= SORT_TILE, else how far above (saturating)
+__global__ __launch_bounds__(SORT_TPB) void k_sort_count(const uint4* boards, uint32_t B, uint32_t thr, uint32_t* cnt, uint16_t* key16, uint32_t* off) {
+    __shared__ uint32_t tab[SORT_KEYS / 2];                 // per key: lanes of this tile (16 bits), later the tile-local index of the key's first lane
+    __shared__ uint32_t reserved[SORT_LANES_PER_WG];        // [tile-local index of a key's first lane] = start of the tile's share of the bucket
+    for (uint32_t j = threadIdx.x; j < SORT_KEYS / 2; j += SORT_TPB) tab[j] = 0;
+    __syncthreads();
+    uint32_t key[SORT_PER_THREAD], rank[SORT_PER_THREAD];
+    const uint32_t i0 = blockIdx.x * SORT_LANES_PER_WG + threadIdx.x;
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int col = 0; col < 4; ++col) {
-            const uint32_t v = (b.r[r] >> (8 * col)) & 0xFFu;
-            constexpr uint32_t TOP = (1u << SORT_CELL_BITS) - 1u;
-            const uint32_t over = v > SORT_TILE ? (v - SORT_TILE + SORT_STEP - 1u) / SORT_STEP : 0u;
-            key = (key << SORT_CELL_BITS) | (over > TOP ? TOP : over);
+    for (uint32_t u = 0; u < SORT_PER_THREAD; ++u) {
+        const uint32_t i = i0 + u * SORT_TPB;
+        key[u] = 0;
+        rank[u] = 0;
+        if (i < B) {
+            key[u] = sort_key(ld_board(boards, i), thr);
+            const uint32_t sh = 16u * (key[u] & 1u);
+            rank[u] = (atomicAdd(&tab[key[u] >> 1], 1u << sh) >> sh) & 0xFFFFu;      // (<= 4 096 per half: no carry between the halves)
         }
-    keys[i] = key;
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t u = 0; u < SORT_PER_THREAD; ++u)
+        if (i0 + u * SORT_TPB < B && rank[u] == 0) {
+            const uint32_t total = (tab[key[u] >> 1] >> (16u * (key[u] & 1u))) & 0xFFFFu;
+            reserved[u * SORT_TPB + threadIdx.x] = atomicAdd(&cnt[key[u]], total);
+        }
+    __syncthreads();
+    uint16_t* const first = reinterpret_cast<uint16_t*>(tab);
+#pragma unroll
+    for (uint32_t u = 0; u < SORT_PER_THREAD; ++u)
+        if (i0 + u * SORT_TPB < B && rank[u] == 0) first[key[u]] = (uint16_t)(u * SORT_TPB + threadIdx.x);
+    __syncthreads();
+#pragma unroll
+    for (uint32_t u = 0; u < SORT_PER_THREAD; ++u) {
+        const uint32_t i = i0 + u * SORT_TPB;
+        if (i < B) {
+            key16[i] = (uint16_t)key[u];
+            off[i] = reserved[first[key[u]]] + rank[u];
+        }
+    }
 }
-constexpr int SORT_KEY_BITS = 16 * SORT_CELL_BITS;
+
+// start[k] = number of lanes with a smaller key; cnt is left zeroed for the next sort
+__global__ __launch_bounds__(SORT_TPB) void k_sort_scan(uint32_t* cnt, uint32_t* start) {
+    constexpr uint32_t PER = SORT_KEYS / SORT_TPB;          // 64 consecutive buckets per thread
+    __shared__ uint32_t wave_sum[SORT_TPB / 64];
+    uint4* const mine = reinterpret_cast<uint4*>(cnt + threadIdx.x * PER);
+    uint4 v[PER / 4];
+    uint32_t sum = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < PER / 4; ++j) {
+        v[j] = mine[j];
+        sum += v[j].x + v[j].y + v[j].z + v[j].w;
+        mine[j] = make_uint4(0, 0, 0, 0);
+    }
+    uint32_t incl = sum;                                    // inclusive scan of the threads' sums: inside the wave, then over the 16 waves
+#pragma unroll
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(incl, d, 64);
+        if ((threadIdx.x & 63u) >= d) incl += up;
+    }
+    if ((threadIdx.x & 63u) == 63u) wave_sum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t base = incl - sum;
+    for (uint32_t wv = 0; wv < (threadIdx.x >> 6); ++wv) base += wave_sum[wv];
+    uint4* const out = reinterpret_cast<uint4*>(start + threadIdx.x * PER);
+#pragma unroll
+    for (uint32_t j = 0; j < PER / 4; ++j) {
+        uint4 o;
+        o.x = base; base += v[j].x;
+        o.y = base; base += v[j].y;
+        o.z = base; base += v[j].z;
+        o.w = base; base += v[j].w;
+        out[j] = o;
+    }
+}
+
+__global__ __launch_bounds__(WG) void k_sort_scatter(const uint16_t* key16, const uint32_t* off, const uint32_t* start, uint32_t B, uint32_t* perm) {
+    const uint32_t i = blockIdx.x * WG + threadIdx.x;
+    if (i < B) perm[start[key16[i]] + off[i]] = i;
+}
 
 struct CarrySet {       // the `state` of QAgent.episode and its orbit indices (prev[cur], oidx[cur])
     uint4* prev;
@@ -2092,10 +2167,9 @@ struct g2048_ctx {
     bool sort_pending = false;          // sort_perm is being (or has been) computed and waits to be applied
     bool sort_issued = false;           // ev_sort_done has been recorded at least once
     uint32_t sort_wait = 0;             // steps until the pending permutation is applied
-    uint64_t *sort_keys = nullptr, *sort_keys_out = nullptr;
-    uint32_t *sort_iota = nullptr, *sort_perm = nullptr;
-    void* sort_temp = nullptr;
-    size_t sort_temp_bytes = 0;
+    uint16_t* sort_key16 = nullptr;     // [B] the lanes' keys
+    uint32_t *sort_off = nullptr, *sort_perm = nullptr;     // [B] offset inside the key's bucket; the permutation
+    uint32_t *sort_cnt = nullptr, *sort_start = nullptr;    // [SORT_KEYS] bucket sizes (zero between sorts), bucket starts
     GameLog log = {0, 0, nullptr, nullptr, nullptr, nullptr};
     uint32_t step_parity = 0;
     float *w = nullptr, *w0 = nullptr, *delta = nullptr;
@@ -2135,6 +2209,7 @@ struct g2048_ctx {
         uint32_t play_dynamic = 2;      // full rounds of k_td_play's lane blocks left to the counter (besides the last, partial one)
         uint32_t sort_every = 16;       // default of g2048_set_lane_sort for new contexts (G2048_SORT_EVERY); 0 = never
         uint32_t sort_min_batch = 1u << 17;     // smaller batches keep their lane order
+        uint32_t sort_tile = SORT_TILE; // key bit of a cell: tile above 2^this (G2048_SORT_TILE)
         uint32_t sort_lag = 2;          // steps between the boards a sort looks at and the step that applies it (G2048_SORT_LAG; 0 = sort in line)
         int hex_bins = 1;               // n = 6: f_6 orbits through k_hex_* (0: k_td_update_tail's scattered atomics)
         int delta_accum = 0;            // multi-GPU epoch delta: 0 = W - W0 when it is asked for, 1 = every add of a step mirrored in an accumulator
@@ -2235,6 +2310,7 @@ void read_knobs(g2048_ctx* c) {
     if (const char* e = getenv("G2048_SORT_EVERY")) k.sort_every = (uint32_t)atoi(e);
     if (const char* e = getenv("G2048_SORT_MIN")) k.sort_min_batch = (uint32_t)atoi(e);
     if (const char* e = getenv("G2048_SORT_LAG")) k.sort_lag = (uint32_t)atoi(e);
+    if (const char* e = getenv("G2048_SORT_TILE")) k.sort_tile = (uint32_t)atoi(e) < 15u ? (uint32_t)atoi(e) : 15u;
     if (const char* e = getenv("G2048_DELTA_ACCUM")) k.delta_accum = atoi(e);
     if (const char* e = getenv("G2048_PLAY_HOT_MIN")) k.play_hot_min = (uint32_t)atoi(e);
 }
@@ -2280,7 +2356,7 @@ int dalloc(g2048_ctx* c, T** p, size_t count) {
     return G2048_OK;
 }
 
-// ---- lane order (LaneSort): see k_sort_keys
+// ---- lane order (LaneSort): see k_sort_count
 LaneSet current_set(g2048_ctx* c) { return LaneSet{c->boards, c->scores, c->rng, c->label, c->flags, c->lane_id, c->last_move}; }
 
 void adopt_set(g2048_ctx* c, const LaneSet& s) {
@@ -2293,44 +2369,38 @@ int lane_sort_prepare(g2048_ctx* c) {
     int rc;
     if ((rc = dalloc(c, &c->alt.boards, B)) || (rc = dalloc(c, &c->alt.scores, B)) || (rc = dalloc(c, &c->alt.rng, B)) ||
         (rc = dalloc(c, &c->alt.label, B)) || (rc = dalloc(c, &c->alt.flags, B)) || (rc = dalloc(c, &c->alt.lane_id, B)) ||
-        (rc = dalloc(c, &c->alt.last_move, B)) || (rc = dalloc(c, &c->sort_keys, B)) || (rc = dalloc(c, &c->sort_keys_out, B)) ||
-        (rc = dalloc(c, &c->sort_iota, B)) || (rc = dalloc(c, &c->sort_perm, B)))
+        (rc = dalloc(c, &c->alt.last_move, B)) || (rc = dalloc(c, &c->sort_key16, B)) || (rc = dalloc(c, &c->sort_off, B)) ||
+        (rc = dalloc(c, &c->sort_perm, B)) || (rc = dalloc(c, &c->sort_cnt, SORT_KEYS)) || (rc = dalloc(c, &c->sort_start, SORT_KEYS)))
         return rc;
     HIP_TRY(c, hipMemsetAsync(c->alt.last_move, 0, B * 2, c->stream));
-    k_iota<<<grid_for(B), WG, 0, c->stream>>>(c->sort_iota, c->B);
-    size_t bytes = 0;
-    if (g2048_lane_sort_pairs(nullptr, &bytes, c->sort_keys, c->sort_keys_out, c->sort_iota, c->sort_perm, c->B, 0, SORT_KEY_BITS, c->stream) != 0)
-        return fail(c, G2048_ERR_HIP, "radix sort: scratch size query failed");
-    hipError_t e = hipMalloc(&c->sort_temp, bytes ? bytes : 16);
-    if (e != hipSuccess) return fail(c, G2048_ERR_NOMEM, "hipMalloc(sort scratch)", e);
-    c->sort_temp_bytes = bytes;
+    HIP_TRY(c, hipMemsetAsync(c->sort_cnt, 0, SORT_KEYS * sizeof(uint32_t), c->stream));
     HIP_TRY(c, hipStreamCreateWithFlags(&c->sort_stream, hipStreamNonBlocking));
     HIP_TRY(c, hipEventCreateWithFlags(&c->ev_sort_go, hipEventDisableTiming));
     HIP_TRY(c, hipEventCreateWithFlags(&c->ev_sort_done, hipEventDisableTiming));
     return G2048_OK;
 }
 
-// keys of the current boards -> sort_perm: position i of the new order takes the lane now at position sort_perm[i].
-// `side`: the keys are taken on the context's stream (the boards as they are now), the sort runs on the side stream and
-// ev_sort_done marks its end; otherwise everything is queued in line.
+// the current boards -> sort_perm: position i of the new order takes the lane now at position sort_perm[i].
+// `side`: the keys are counted on the context's stream (the boards as they are now); the scan and the scatter run on the
+// side stream and ev_sort_done marks their end; otherwise everything is queued in line.
 int lane_sort_permutation(g2048_ctx* c, bool side) {
     if (int rc = lane_sort_prepare(c)) return rc;
-    if (c->sort_issued) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_sort_done, 0));       // (an abandoned sort may still be reading the key buffer)
-    k_sort_keys<<<grid_for(c->B), WG, 0, c->stream>>>(c->boards, c->B, c->sort_keys);
+    if (c->sort_issued) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_sort_done, 0));       // (an abandoned sort may still be reading its buffers)
+    k_sort_count<<<(c->B + SORT_LANES_PER_WG - 1) / SORT_LANES_PER_WG, SORT_TPB, 0, c->stream>>>(c->boards, c->B, c->knob.sort_tile, c->sort_cnt, c->sort_key16,
+                                                                                           c->sort_off);
     hipStream_t st = c->stream;
     if (side) {
         HIP_TRY(c, hipEventRecord(c->ev_sort_go, c->stream));
         HIP_TRY(c, hipStreamWaitEvent(c->sort_stream, c->ev_sort_go, 0));
         st = c->sort_stream;
     }
-    size_t bytes = c->sort_temp_bytes;
-    if (g2048_lane_sort_pairs(c->sort_temp, &bytes, c->sort_keys, c->sort_keys_out, c->sort_iota, c->sort_perm, c->B, 0, SORT_KEY_BITS, st) != 0)
-        return fail(c, G2048_ERR_HIP, "radix sort failed");
+    k_sort_scan<<<1, SORT_TPB, 0, st>>>(c->sort_cnt, c->sort_start);
+    k_sort_scatter<<<grid_for(c->B), WG, 0, st>>>(c->sort_key16, c->sort_off, c->sort_start, c->B, c->sort_perm);
     if (side) {
         HIP_TRY(c, hipEventRecord(c->ev_sort_done, c->sort_stream));
         c->sort_issued = true;
     }
-    return G2048_OK;
+    return launched(c, "lane re-order");
 }
 
 // every entry point that addresses lanes by index calls this first: back to identity order (a no-op unless a TD step
@@ -3095,7 +3165,7 @@ int g2048_destroy(g2048_ctx* c) {
     void* bufs[] = {c->log.moves, c->log.start, c->log.final, c->log.meta, c->boards, c->scores, c->rng, c->prev[0], c->prev[1], c->oidx[0], c->oidx[1], c->label, c->flags, c->dw1, c->qstate,
                     c->qdw,    c->qcount, c->last_move, c->w,      c->w0,  c->delta,   c->stats,   c->scratch, c->slices, c->statbuf, c->D, c->Dcnt, c->D2, c->Dcnt2, c->pack, c->lane_id,
                     c->alt.boards, c->alt.scores, c->alt.rng, c->alt.label, c->alt.flags, c->alt.lane_id, c->alt.last_move,
-                    c->sort_keys, c->sort_keys_out, c->sort_iota, c->sort_perm, c->sort_temp,
+                    c->sort_key16, c->sort_off, c->sort_perm, c->sort_cnt, c->sort_start,
                     c->hex.count, c->hex.base, c->hex.cursor, c->hex.pairs, c->hex.work, c->hex.nwork};
     for (void* p : bufs)
         if (p && (p != (void*)c->w || c->owns_table)) (void)hipFree(p);
@@ -3528,6 +3598,16 @@ int g2048_set_lane_sort(g2048_ctx* c, uint32_t every) {
     c->steps_since_sort = 0;
     c->sort_pending = false;
     return G2048_OK;
+}
+
+// test hook: run the lane re-order on the current boards, in line, and hand back what it produced — perm (position i of the
+// new order takes the lane at position perm[i]) and every position's key.  The lane order itself is left as it is.
+int g2048_debug_lane_order(g2048_ctx* c, uint32_t* perm, uint16_t* keys) {
+    if (!c || !perm || !keys) return c ? fail(c, G2048_ERR_ARG, "null output") : G2048_ERR_ARG;
+    if (int rc = bind(c)) return rc;
+    if (int rc = lane_sort_permutation(c, false)) return rc;
+    if (int rc = d2h(c, perm, c->sort_perm, (size_t)c->B * 4)) return rc;
+    return d2h(c, keys, c->sort_key16, (size_t)c->B * 2);
 }
 
 int g2048_set_update_mode(g2048_ctx* c, int mode) {

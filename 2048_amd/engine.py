@@ -234,6 +234,12 @@ class Engine:
         """Re-order the lanes by their big-tile pattern every `every` TD steps (0 = never); invisible to the host."""
         self._c(self.lib.g2048_set_lane_sort(self.ctx, int(every)))
 
+    def debug_lane_order(self):
+        """(perm, keys) of the lane re-order run on the current boards (test hook; the order itself is not changed)."""
+        perm, keys = np.zeros(self.B, np.uint32), np.zeros(self.B, np.uint16)
+        self._c(self.lib.g2048_debug_lane_order(self.ctx, _buf(perm), _buf(keys)))
+        return perm, keys
+
     def set_update_mode(self, mode):
         """1 = LDS-owner update kernel (default), 0 = global fp32 atomics."""
         self._c(self.lib.g2048_set_update_mode(self.ctx, int(mode)))

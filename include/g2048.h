@@ -138,10 +138,14 @@ int g2048_update(g2048_ctx* ctx, const uint8_t* states /* [count][16] */, const 
 int g2048_td_steps(g2048_ctx* ctx, float alpha, uint32_t nsteps);
 /* Lane order in memory.  k_td_play is bound by the L1 misses of its table gathers, and lanes whose big tiles sit in the
  * same cells touch the same cache lines: with every > 0 each `every`-th TD step re-orders the lanes by their big-tile
- * pattern (a radix sort; the step reads its lanes through the permutation).  Invisible through this ABI — every entry
+ * pattern (a hand-written counting sort on one key bit per cell, three launches; the step reads its lanes through the
+ * permutation).  Invisible through this ABI — every entry
  * point that addresses lanes by index restores the identity order first (one copy pass) — and to the results: a lane's
  * game does not depend on where it sits.  Default 16; 0: never.  Batches below 2^17 lanes and n < 4 keep their order. */
 int g2048_set_lane_sort(g2048_ctx* ctx, uint32_t every);
+/* test hook: the permutation the re-order would apply to the current boards (position i takes the lane at perm[i]) and the
+ * key of every position; the lane order is left alone */
+int g2048_debug_lane_order(g2048_ctx* ctx, uint32_t* perm /* [B] */, uint16_t* keys /* [B] */);
 /* how the step's records are added to the table: 1 (default) = LDS-owner kernel (workgroups own 128 KiB table
  * slices in LDS, no global atomics for n <= 5), 0 = one global fp32 atomic per slot.  Same sums either way. */
 int g2048_set_update_mode(g2048_ctx* ctx, int mode);

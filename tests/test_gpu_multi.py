@@ -5,6 +5,7 @@ import importlib
 import json
 import os
 import subprocess
+import time
 import sys
 
 import numpy as np
@@ -144,6 +145,42 @@ def test_bench_self_launch_two_ranks_gloo():
     assert line['n_gpus'] == 2 and line['steps'] == 12 and line['warmup'] == 3 and line['scaling'] == 'weak'
     assert line['value'] > 0 and 'all-reduce every 5 steps' in line['config']['parallelism']
     assert line['roofline']['frac'] <= 1.0
+    assert line['comm']['nranks_seen'] == 2 and line['comm']['allreduce_plus_apply_ms'] > 0
+
+
+def _bench_two_ranks(*extra, timeout=900):
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--no-cpu-baseline', *extra]
+    env = dict(os.environ)
+    env.pop('WORLD_SIZE', None)
+    env.pop('RANK', None)
+    t0 = time.monotonic()
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+    return res, time.monotonic() - t0
+
+
+@pytest.mark.parametrize('rule', ['sum', 'mean'])
+def test_bench_two_ranks_n6_exchange(rule):
+    """BASELINE config 5's exchange rehearsed with two ranks: the n = 6 table (382.65 MB of deltas per epoch, 765 MB under
+    the mean rule) goes through run_epochs' all-reduce.  --comm native: with both ranks on one GPU ncclCommInitRank
+    refuses, and BOTH ranks must then fall back to torch.distributed together (parallel.make_sync)."""
+    res, _ = _bench_two_ranks('--n-tuple', '6', '--batch', '65536', '--steps', '6', '--warmup', '2', '--condition', '4', '--epoch', '3',
+                              '--repeats', '1', '--rule', rule, '--comm', 'native')
+    assert res.returncode == 0, res.stderr[-3000:]
+    line = json.loads(res.stdout.strip().splitlines()[-1])
+    assert line['n_gpus'] == 2 and line['config']['n_tuple'] == 6 and line['value'] > 0
+    comm = line['comm']
+    assert comm['nranks_seen'] == 2 and comm['exchanges_per_timed_region'] == 2
+    assert comm['payload_bytes'] == 95662848 * 4 * (2 if rule == 'mean' else 1)
+    assert comm['allreduce_plus_apply_ms'] > 0
+
+
+def test_bench_rank_killed_mid_run_ends_the_job():
+    """One rank dies after the warm-up, between two exchanges: the survivor would wait in the next all-reduce; the parent
+    must notice, terminate it and exit non-zero within seconds, without a result line."""
+    res, dt = _bench_two_ranks('--batch', '65536', '--steps', '12', '--warmup', '3', '--condition', '8', '--epoch', '5', '--comm', 'torch',
+                               '--fault-inject', 'exit@1:run', timeout=300)
+    assert res.returncode != 0 and dt < 120
+    assert 'rank 1 exited with code 3' in res.stderr and res.stdout.strip() == ''
 
 
 def test_qagent_train_run_two_ranks(tmp_path):

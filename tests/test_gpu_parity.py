@@ -380,6 +380,27 @@ def test_lane_sort_is_invisible(n, lag, monkeypatch):
     eng.close()
 
 
+@pytest.mark.parametrize('B', [1, 777, 4096, 4097, (1 << 18) + 13])
+def test_lane_order_is_a_sorted_permutation(B):
+    """The hand-written lane re-order (k_sort_count / k_sort_scan / k_sort_scatter): its output is a permutation of the
+    positions, non-decreasing in the key, and the key is one bit per cell — tile above 32 — row 0 in the top nibble.  Ragged
+    sizes around the 4 096-lane tile of a workgroup; run twice (the bucket counters must be back at zero)."""
+    eng = Engine(B, n=4, seed=31 + B)
+    eng.step_random(150)                                     # mid-game boards: many distinct patterns
+    boards = eng.get_boards().reshape(B, 16)
+    want = np.zeros(B, np.uint32)
+    for cell in range(16):
+        r, c = divmod(cell, 4)
+        want |= (boards[:, cell] > 5).astype(np.uint32) << (4 * (3 - r) + c)
+    for _ in range(2):
+        perm, keys = eng.debug_lane_order()
+        assert np.array_equal(keys, want.astype(np.uint16))
+        assert np.array_equal(np.sort(perm), np.arange(B, dtype=np.uint32))
+        assert np.all(np.diff(keys[perm].astype(np.int64)) >= 0)
+    assert len(np.unique(keys)) > 1 or B == 1
+    eng.close()
+
+
 def test_lane_sort_same_games_at_scale():
     """Same seed with and without lane re-ordering, auto-reset on, 2^17 lanes, n = 4, 40 steps.  A lane's game does not
     depend on where the lane sits, so both runs play the same games — up to the run-to-run noise any two runs have (the
