@@ -205,7 +205,8 @@ class QAgent:
     def weights(self):
         if self._engine is None and self._pending_weights is None:
             return None
-        flat = self.engine.get_weights()
+        # (weights handed over before the first use of the device can be read back — and pickled — without one)
+        flat = self._pending_weights if self._engine is None else self.engine.get_weights()
         offs, sizes = feature_layout(self.n)
         return [flat[o:o + s] for o, s in zip(offs, sizes)]
 
@@ -561,9 +562,11 @@ class QAgent:
                     f'Looking forward: depth={depth}, width={width}, since_empty={since_empty}')
         began = time.time()
         owner = getattr(estimator, '__self__', None)
-        on_device = isinstance(owner, QAgent) and depth == 0 and not limit_tile and not verbose and not stopper
+        on_device = (isinstance(owner, QAgent) and getattr(estimator, '__name__', '') == 'evaluate' and not verbose and not stopper)
         if on_device:
-            results = owner._trial_batched(num, game_init)
+            # all `num` games at once: depth 0 entirely on the device (with its game records), depth > 0 with every game's
+            # look-ahead tree in the same level-by-level batches (2048_amd/lookahead.py)
+            results = owner._trial_batched(num, game_init, depth=depth, width=width, since_empty=since_empty, limit_tile=limit_tile)
             for i, game in enumerate(results):
                 display(f'game {i}, result {game.score}, moves {game.odometer}, achieved {1 << np.max(game.row)}')
         else:
@@ -608,29 +611,114 @@ class QAgent:
             lines.append(f'time per shuffle = {round(elapsed / shuffles * 1000, 2)} ms')
         return '\n'.join(lines)
 
-    def _trial_batched(self, num, game_init=None):
-        """`num` greedy games at once on the device (alpha = 0: no records, no learning), each to its end."""
-        eng = Engine(num, seed=self.seed + 77, lane0=1 << 41, share_table_of=self.engine)
+    TRIAL_LOG_BYTES = 1 << 31         # device memory the game records of one trial may take
+
+    def _trial_batched(self, num, game_init=None, depth=0, width=1, since_empty=6, limit_tile=0):
+        """`num` greedy games at once (r_learning.py:362-376 runs them one after the other), each a full reference
+        `Game`: row, score, odometer, moves, tiles, starting_position — what `results[0].save_game` / show.py's replay need
+        (game_logic.py:163-167 appends every move, :118-121 every tile).
+        depth 0: on the device, alpha = 0 (no records, no learning), the lanes' game logs switched on for all of them;
+        `self.trial_seed = (seed, lane0)` fixes the lanes' RNG streams (default: away from the training lanes).
+        depth > 0 or limit_tile: `_trial_lookahead`."""
+        if depth > 0 or limit_tile:
+            return self._trial_lookahead(num, game_init, depth, width, since_empty, limit_tile)
+        seed, lane0 = getattr(self, 'trial_seed', (self.seed + 77, 1 << 41))
+        eng = Engine(num, seed=seed, lane0=lane0, share_table_of=self.engine)
         eng.set_auto_reset(False)
         if game_init is not None:
             eng.set_boards(np.repeat(np.asarray(game_init.row, np.uint8)[None], num, axis=0))
             eng.set_scores(np.full(num, game_init.score, np.int32))
-        start_boards = eng.get_boards()
-        odometer = np.zeros(num, np.int64)
-        while True:
-            eng.td_steps(0.0, 1)
-            lm = eng.last_move()
-            odometer += (lm >> 2) & 1
-            if not ((lm >> 2) & 1).any():
-                break
-        boards, scores = eng.get_boards(), eng.get_scores()
-        eng.close()
+        capacity = int(min(self.LOG_CAPACITY, max(2048, self.TRIAL_LOG_BYTES // (4 * num))))
+        eng.log_enable(num, capacity)
+        eng.stats_reset()
+        while eng.stats()['episodes'] < num:                   # every lane ends exactly once (auto-reset is off)
+            eng.td_steps(0.0, 256)
+        meta = eng.log_meta()
         games = []
-        for i in range(num):
-            g = Game(score=int(scores[i]), row=boards[i])
-            g.starting_position = start_boards[i].astype(np.int32)
-            g.odometer = int(odometer[i])
-            games.append(g)
+        for lane in range(num):
+            length, score, flags = int(meta[lane, 3]), int(meta[lane, 4]), int(meta[lane, 7])
+            if flags & 4:                                      # longer than the record's capacity: the outcome without the moves
+                game = Game(score=score, row=eng.log_final(lane, 0).astype(np.int32))
+                game.starting_position, game.odometer = eng.log_game(lane, 0)[1].astype(np.int32), length
+            else:
+                game = self._game_from_log(eng, lane, 0, length, score)
+                game.moves.pop()                               # trial_run ends without the -1 that episode() appends
+            if game_init is not None:                          # the games continue game_init's record
+                game.starting_position = np.array(game_init.starting_position, np.int32)
+                game.moves, game.tiles = list(game_init.moves) + game.moves, list(game_init.tiles) + game.tiles
+                game.odometer += game_init.odometer
+            games.append(game)
+        eng.close()
+        return games
+
+    def _trial_lookahead(self, num, game_init, depth, width, since_empty, limit_tile):
+        """Game.trial_run with look-ahead (game_logic.py:150-183, 214-243) for `num` games in lock step: one
+        g2048_boards_move_all for the candidates of all games, ONE expectimax tree batch for all of them
+        (lookahead.expectimax_values: the children of every node of every game per level), first maximum per game, then
+        the new tiles.  New tiles and sampled chance nodes come from a NumPy generator (the reference draws both from
+        Python's `random`), seeded by `self.trial_seed`."""
+        from . import lookahead
+        eng = self.engine
+        seed = getattr(self, 'trial_seed', (self.seed + 77, 1 << 41))[0]
+        rng = np.random.default_rng(seed)
+        sampler = lookahead.random_sampler(rng)
+
+        def spawn(b):
+            """One new tile on every board of b [M,16] (game_logic.py:112-121); returns (tile, cell)."""
+            keys = rng.random(b.shape)
+            keys[b != 0] = 2.0
+            cell = np.argmin(keys, axis=1)                     # a uniformly chosen empty cell
+            tile = np.where(rng.integers(0, 10, len(b)) == 0, 2, 1).astype(np.uint8)
+            b[np.arange(len(b)), cell] = tile
+            return tile, cell
+
+        boards = np.zeros((num, 16), np.uint8)
+        scores = np.zeros(num, np.int64)
+        if game_init is not None:
+            boards[:] = np.asarray(game_init.row, np.uint8).reshape(16)
+            scores[:] = game_init.score
+        else:
+            spawn(boards)
+            spawn(boards)
+        start = boards.copy()
+        moves, tiles = [[] for _ in range(num)], [[] for _ in range(num)]
+        live = np.arange(num)
+        while len(live):
+            after, reward, changed = eng.boards_move_all(boards[live])
+            go = changed != 0                                  # game over <=> no direction changes the board
+            if limit_tile:
+                go &= boards[live].max(axis=1) < limit_tile
+            live, after, reward, changed = live[go], after[go], reward[go], changed[go]
+            if not len(live):
+                break
+            gi, di = np.nonzero((changed[:, None] >> np.arange(4)[None, :]) & 1)
+            vals = lookahead.expectimax_values(eng, after[gi, di], depth, width, since_empty, sampler)
+            best = np.full(len(live), -np.inf)
+            np.maximum.at(best, gi, vals)
+            first = np.full(len(live), 4)
+            hit = vals >= best[gi]
+            np.minimum.at(first, gi[hit], di[hit])             # strict '>' from -inf keeps the first maximum
+            fallback = np.full(len(live), 4)
+            np.minimum.at(fallback, gi, di)                    # (all values NaN: still a legal move)
+            first = np.where(first < 4, first, fallback)
+            idx = np.arange(len(live))
+            chosen = after[idx, first].reshape(-1, 16).copy()
+            tile, cell = spawn(chosen)
+            boards[live] = chosen
+            scores[live] += reward[idx, first]
+            for g, d, t, c in zip(live.tolist(), first.tolist(), tile.tolist(), cell.tolist()):
+                moves[g].append(d)
+                tiles[g].append((t, (c >> 2, c & 3)))
+        games = []
+        for g in range(num):
+            game = Game(score=int(scores[g]), row=boards[g].reshape(4, 4).astype(np.int32))
+            game.starting_position = start[g].reshape(4, 4).astype(np.int32)
+            game.moves, game.tiles, game.odometer = moves[g], tiles[g], len(moves[g])
+            if game_init is not None:
+                game.starting_position = np.array(game_init.starting_position, np.int32)
+                game.moves, game.tiles = list(game_init.moves) + game.moves, list(game_init.tiles) + game.tiles
+                game.odometer += game_init.odometer
+            games.append(game)
         return games
 
 

@@ -236,7 +236,7 @@ class Engine:
 
     def debug_lane_order(self):
         """(perm, keys) of the lane re-order run on the current boards (test hook; the order itself is not changed)."""
-        perm, keys = np.zeros(self.B, np.uint32), np.zeros(self.B, np.uint16)
+        perm, keys = np.zeros(self.batch, np.uint32), np.zeros(self.batch, np.uint16)
         self._c(self.lib.g2048_debug_lane_order(self.ctx, _buf(perm), _buf(keys)))
         return perm, keys
 

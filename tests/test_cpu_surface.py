@@ -43,3 +43,50 @@ def test_train_run_schedule_matches_reference(golden):
     want = str(g['log']).split('\n')
     got = '\n'.join(keep).split('\n')
     assert got == want, next((i, a, b) for i, (a, b) in enumerate(zip(got + [None], want + [None])) if a != b)
+
+
+# ---- f-2 in the reverse direction: pickles written by THIS build, read by the reference.
+# tests/golden/make_built_pickles.py wrote built_*.pkl with 2048_amd's own classes; tests/golden/make_golden3.py loaded
+# them with the imported reference (pickle.load + np_to_list, r_learning.py:189-200; Game.load_game + replay,
+# game_logic.py:82-86,246-269) and recorded what it saw in built_pickles.npz.
+def test_build_written_pickles_name_only_reference_paths(tmp_path, monkeypatch):
+    """What the build writes today is what the fixture was made from, and it names nothing the reference lacks: the classes
+    and the agent's `features` function travel as game2048.r_learning.* / game2048.game_logic.* paths."""
+    import importlib.util
+    import os
+    import shutil
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    work = tmp_path / 'golden'
+    work.mkdir()
+    shutil.copy(os.path.join(here, 'episode_n2.npz'), work)
+    spec = importlib.util.spec_from_file_location('make_built_pickles', os.path.join(here, 'make_built_pickles.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    monkeypatch.setattr(mod, 'HERE', str(work))
+    mod.main()
+    for name in ('built_agent_local.pkl', 'built_agent_params.pkl', 'built_agent_weights.pkl', 'built_game.pkl'):
+        fresh, committed = (work / name).read_bytes(), open(os.path.join(here, name), 'rb').read()
+        assert fresh == committed, f'{name}: the build no longer writes what the reference was shown'
+        assert b'2048_amd' not in fresh and b'_alias' not in fresh
+
+
+def test_reference_reads_build_written_pickles(golden):
+    """The reference's view of those pickles equals what was put in: evaluate() of the loaded agent = the oracle's value
+    with the same weights (local and s3 form), the training state survives, update() still works on the loaded agent,
+    and Game.replay() rebuilds the golden episode from the build's Game record."""
+    from oracle import ref_scalar as rs
+    from tests.golden import formulas
+    g = golden('built_pickles.npz')
+    agent = rs.Agent(n=3, weights=formulas.weights(3, scale=2.0 ** -4).astype(np.float64))
+    want = np.array([agent.evaluate(b.astype(np.int32)) for b in g['boards']])
+    assert np.array_equal(g['local_values'], want) and np.array_equal(g['s3_values'], want)
+    assert g['local_attrs'].tolist() == [3, 52, 4321, 98765, 12, 777] and g['local_alpha'].tolist() == [0.125, 0.5, 0.03]
+    assert g['local_signature'].tolist() == [52] and g['local_history'].tolist() == [100, 250, 400] and str(g['s3_name']) == 'built_s3'
+    b5 = g['boards'][5].astype(np.int32)
+    before = agent.evaluate(b5)
+    agent.update(b5, 0.125)
+    assert float(g['local_update_gain']) == agent.evaluate(b5) - before
+    ep = golden('episode_n2.npz')
+    assert np.array_equal(g['game_chain_rows'], ep['boards']) and np.array_equal(g['game_chain_scores'], ep['scores'])
+    assert np.array_equal(g['game_chain_moves'], ep['moves'].astype(np.int64))
+    assert str(g['game_str']).endswith(f"score = {int(ep['final_score'])} moves = {len(ep['tiles'])} reached {1 << int(ep['final_board'].max())}")

@@ -138,6 +138,70 @@ def test_trial_runs_greedy_games_on_the_device(api):
     assert any('average score of 64 runs' in ln for ln in lines) and any('2048 reached in' in ln for ln in lines)
 
 
+def test_trial_reproduces_the_reference_trial(api, golden, tmp_path):
+    """QAgent.trial at depth 0 (r_learning.py:348-406 -> Game.trial_run, game_logic.py:170-183): the fixture is the
+    REFERENCE's own trial of 8 games (tests/golden/make_golden3.py: dyadic n=4 table, game g drawing its tiles from lane
+    lane0 + g of the RNG spec).  The device plays the 8 games at once and must return the same Games in the same order —
+    scores, odometers, final rows, starting positions, every move and every tile — and the saved best game must replay."""
+    g = golden('trial.npz')
+    n = int(g['n'])
+    agent = api.QAgent(name='t', storage='local', console='local', n=n, with_weights=False)
+    sizes = formulas.feature_sizes(n)
+    flat = formulas.weights(n, scale=float(g['scale'])).astype(np.float32)
+    offs = np.concatenate([[0], np.cumsum(sizes)[:-1]])
+    agent.weights = [flat[o:o + s] for o, s in zip(offs, sizes)]
+    agent.trial_seed = (int(g['seed']), int(g['lane0']))
+    lines = []
+    import builtins
+    real_print = builtins.print
+    builtins.print = lambda *a, **k: lines.append(' '.join(str(x) for x in a))
+    game_file = str(tmp_path / 'best.pkl')
+    try:
+        results = api.QAgent.trial(estimator=agent.evaluate, num=len(g['scores']), storage='local', console='local', game_file=game_file)
+    finally:
+        builtins.print = real_print
+    assert [r.score for r in results] == g['scores'].tolist() and [r.odometer for r in results] == g['odometers'].tolist()
+    for i, r in enumerate(results):
+        k = int(g['odometers'][i])
+        assert np.array_equal(r.row, g['rows'][i]) and np.array_equal(r.starting_position, g['starts'][i])
+        assert r.moves == g['moves'][i, :k].tolist()
+        assert [(t, p[0] * 4 + p[1]) for t, p in r.tiles] == [tuple(x) for x in g['tiles'][i, :k].tolist()]
+    # the reference's closing message, minus the timing lines
+    want = [ln for ln in str(g['summary']).split('\n') if 'time' not in ln and 'shuffles' not in ln and not ln.startswith('game ')]
+    got = [ln for ln in '\n'.join(lines).split('\n') if 'time' not in ln and 'shuffles' not in ln and not ln.startswith('game ') and 'Best game saved' not in ln and '-----' not in ln]
+    assert got == want, (got[:12], want[:12])
+    best = api.Game.load_game(game_file)                       # what show.py option 1 replays
+    best.moves.append(-1)
+    chain = best.replay(verbose=False)
+    assert np.array_equal(chain[best.odometer][0], g['rows'][0]) and chain[best.odometer][1] == int(g['scores'][0])
+
+
+def test_trial_with_lookahead_plays_all_games_in_one_batch(api):
+    """depth > 0 (game_logic.py:214-243 under trial_run): all games' trees go through lookahead.expectimax_values together.
+    Every returned Game is a full record that replays to its final position; looking ahead does not play worse than greedy
+    with the same (briefly trained) table."""
+    agent = api.QAgent(name='t', storage='local', console='local', n=4, alpha=0.25, batch=4096, seed=5)
+    agent.print = lambda *a, **k: None
+    agent.train_run(num_eps=40000, saving=False)
+    import builtins
+    real_print = builtins.print
+    builtins.print = lambda *a, **k: None
+    try:
+        deep = api.QAgent.trial(estimator=agent.evaluate, num=24, depth=1, width=2, since_empty=8, storage='local', console='local')
+        flat = api.QAgent.trial(estimator=agent.evaluate, num=256, storage='local', console='local')
+        capped = api.QAgent.trial(estimator=agent.evaluate, num=8, limit_tile=7, storage='local', console='local')
+    finally:
+        builtins.print = real_print
+    assert len(deep) == 24 and deep[0].score >= deep[-1].score
+    for game in deep[:6] + flat[:3]:
+        assert game.game_over(game.row) and game.odometer == len(game.moves) == len(game.tiles)
+        game.moves.append(-1)
+        chain = game.replay(verbose=False)
+        assert np.array_equal(chain[game.odometer][0], game.row) and chain[game.odometer][1] == game.score
+    assert np.mean([g.score for g in deep]) > 0.8 * np.mean([g.score for g in flat])
+    assert all(g.row.max() >= 7 or g.game_over(g.row) for g in capped) and any(g.row.max() == 7 for g in capped)
+
+
 def test_batched_training_learns(api):
     """Learning sanity (BASELINE.md quality rows are per 20 000+ episodes of the reference; here: the mean score of
     finished games must rise clearly within a few game generations of 4096 concurrent episodes, n = 4)."""
