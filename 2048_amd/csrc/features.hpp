@@ -357,6 +357,26 @@ constexpr uint32_t COSET_MASK[6] = {0x27u, 0x27u, 0x55u, 0x1Bu, 0x01u, 0x55u};
 // the two f_6 orbits (k_td_update_tail): the corner blocks' representative (feature 21) is fixed by nothing, the middle
 // blocks' (feature 22) by the left-right mirror
 constexpr uint32_t HEX_COSET_MASK[2] = {0xFFu, 0x1Bu};
+// n = 2, 3 (round 3): the same reduction.  f_2's 24 pairs fall into 4 orbits (the 8 border pairs that touch a corner, the
+// 8 pairs that run from the border inwards, the 4 middle border pairs, the 4 pairs of the centre square); f_3's 52 triples
+// into 8 (border lines, inner lines, and the L-shapes of the corner / edge / centre windows by which cell they leave out).
+// A record then costs 24 (n = 2) or 52 (n = 3) LDS adds instead of 8 x 24 = 192 or 8 x 52 = 416, into orbit tables of
+// 4 x 256 or 8 x 4 096 slots.  Representatives and coset masks were found with the host build of these headers
+// (tests/test_hostcheck_logic.py repeats the search) and find_orbits checks them at context creation.
+template <int N> struct SmallOrbits;
+template <> struct SmallOrbits<2> {
+    static constexpr int COUNT = 4, PER_CHUNK = 4;
+    static constexpr uint32_t SIZE = 256u;
+    static constexpr int rep(int o) { constexpr int R[4] = {0, 1, 4, 5}; return R[o]; }
+    static constexpr uint32_t mask(int o) { constexpr uint32_t M[4] = {0xFFu, 0xFFu, 0x27u, 0x27u}; return M[o]; }
+};
+template <> struct SmallOrbits<3> {
+    static constexpr int COUNT = 8, PER_CHUNK = 4;
+    static constexpr uint32_t SIZE = 4096u;
+    static constexpr int rep(int o) { constexpr int R[8] = {0, 1, 16, 17, 18, 20, 21, 24}; return R[o]; }
+    static constexpr uint32_t mask(int o) { constexpr uint32_t M[8] = {0xFFu, 0xFFu, 0x55u, 0xFFu, 0xFFu, 0x55u, 0xFFu, 0x55u}; return M[o]; }
+};
+
 // the j-th visited image of orbit variant V
 constexpr uint32_t coset_rank(uint32_t mask, uint32_t g) {
     uint32_t r = 0;

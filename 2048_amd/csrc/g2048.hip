@@ -506,105 +506,86 @@ __device__ __forceinline__ void load_hot_set(float* hot, const float* __restrict
     __syncthreads();
 }
 
-// choose<N> with the hot set (n >= 4: features 0..16 are the four-cell tuples), in two phases so that no gather needs a
+// choose<N> with the hot set (n = 4, 5: features 0..16 are the four-cell tuples), in two phases so that no gather needs a
 // second result register and none waits for another: (A) EVERY lane reads the LDS copy at t mod HOT (a wrong word for the
 // cold lanes, at LDS speed); (B) the cold lanes then overwrite it with a global load under their exec mask.  The L1 sees
 // the cold lanes only.  (Round 2's first version — every cell <= 32 through a base-6 index, ONE flat load per gather whose
 // lanes point into either aperture — removed 44 % of the L1's tag look-ups and no time: a flat load still walks every lane
 // through the address unit and the tag stage.  A ds_read / global_load pair under complementary exec masks, LDS second,
 // makes the compiler wait for each global load before it issues the ds_read into the same register.)
+//
+// The 68 results live in VGPRs THE COMPILER DOES NOT HAVE (round 3).  Round 2 issued the masked loads from inline asm into
+// ordinary variables ("+v"(x[f])): the compiler believed x[f] valid from that point on while the load was still in flight
+// until a fence further down, and was free to copy or spill it in between — tools/check_codeobj.py found it doing exactly
+// that in the shipped k_td_play<5, 512, true, true> (v_mov_b32 v209, v2 some 1 900 instructions after global_load_dword v2,
+// no wait in between: right only because the load had long returned).  Now the kernels that use this path are compiled with
+// amdgpu_num_vgpr(PLAY_HOT_COMPILER_VGPRS): the register allocator owns v0 .. v171, and v172 .. v239 are named only inside
+// the asm statements below — the LDS read, the masked global load, and, behind `s_waitcnt vmcnt(0)`, the v_add_f32 that
+// consumes each of them.  Nothing the compiler generates can touch a result in flight, by construction, and
+// tools/check_codeobj.py (run by __graft_entry__.build()) still checks the code object: no scratch, no instruction that
+// names a load's destination before a wait that covers it.
+#define G2048_HOT_REGS0(M) M(0, "v172") M(1, "v173") M(2, "v174") M(3, "v175") M(4, "v176") M(5, "v177") M(6, "v178") M(7, "v179") M(8, "v180") M(9, "v181") M(10, "v182") M(11, "v183") M(12, "v184") M(13, "v185") M(14, "v186") M(15, "v187") M(16, "v188")
+#define G2048_HOT_REGS1(M) M(0, "v189") M(1, "v190") M(2, "v191") M(3, "v192") M(4, "v193") M(5, "v194") M(6, "v195") M(7, "v196") M(8, "v197") M(9, "v198") M(10, "v199") M(11, "v200") M(12, "v201") M(13, "v202") M(14, "v203") M(15, "v204") M(16, "v205")
+#define G2048_HOT_REGS2(M) M(0, "v206") M(1, "v207") M(2, "v208") M(3, "v209") M(4, "v210") M(5, "v211") M(6, "v212") M(7, "v213") M(8, "v214") M(9, "v215") M(10, "v216") M(11, "v217") M(12, "v218") M(13, "v219") M(14, "v220") M(15, "v221") M(16, "v222")
+#define G2048_HOT_REGS3(M) M(0, "v223") M(1, "v224") M(2, "v225") M(3, "v226") M(4, "v227") M(5, "v228") M(6, "v229") M(7, "v230") M(8, "v231") M(9, "v232") M(10, "v233") M(11, "v234") M(12, "v235") M(13, "v236") M(14, "v237") M(15, "v238") M(16, "v239")
+#define PLAY_HOT_COMPILER_VGPRS 172
+#define PLAY_HOT_LAST_VGPR "v239"
+
 template <int N>
 __device__ __forceinline__ Choice choose_hot(const float* __restrict__ w, const float* hot_, const Moves4& mv) {
     constexpr int F = Shape<N>::F;
-    static_assert(N >= 4, "the hot set covers the four-cell features");
-    // (`hot_` IS the kernel's __shared__ array, which the compiler cannot see through the lambda it arrives by: ds_read, not flat)
-    const __attribute__((address_space(3))) float* hot = (const __attribute__((address_space(3))) float*)hot_;
+    static_assert(N == 4 || N == 5, "the hot set covers the four-cell features; all four directions' gathers are in flight together");
+    // (`hot_` IS the kernel's __shared__ array, which the compiler cannot see through the lambda it arrives by)
+    const uint32_t hot_base = (uint32_t)(size_t)(const __attribute__((address_space(3))) float*)hot_;
+    asm volatile("" ::: PLAY_HOT_LAST_VGPR);        // (counts the registers above the allocator's range into the kernel's VGPR budget)
     Choice c;
     c.action = -1;
     c.value = -INFINITY;
     int first_valid = -1;
-#define G2048_HOT_A(M, X, T, MS)                                                            \
-    float X[F];                                                                             \
-    uint32_t T[17], MS[F];                                                                  \
+    // phase A + B of one direction: T[f] = the gather's place in its table (memory order), hot iff T[f] < HOT_PER_FEATURE
+#define G2048_HOT_LDS(f, reg) asm volatile("ds_read_b32 " reg ", %0" ::"v"(hot_base + (((uint32_t)(f) * HOT_PER_FEATURE + (T_[f] & (HOT_PER_FEATURE - 1u))) << 2)));
+#define G2048_HOT_GLB(f, reg) \
+    if (changed_ && T_[f] >= HOT_PER_FEATURE) asm volatile("global_load_dword " reg ", %0, %1" ::"v"(((uint32_t)(f) * 65536u + T_[f]) << 2), "s"(w));
+#define G2048_HOT_DIR(M, REGS, XC)                                                          \
+    float XC[F > 17 ? F - 17 : 1];                                                          \
     {                                                                                       \
-        uint32_t s[F];                                                                      \
-        feature_slots<N>(pack_board((M).after), s);                                         \
-        memory_slots<N>(pack_board((M).after), MS);         /* (used for the features behind the four-cell ones) */ \
-        _Pragma("unroll") for (int f = 0; f < 17; ++f) {                                    \
-            T[f] = bit_transpose16(s[f] & 0xFFFFu);                                         \
-            X[f] = hot[(uint32_t)f * HOT_PER_FEATURE + (T[f] & (HOT_PER_FEATURE - 1u))];   \
-        }                                                                                   \
+        uint32_t s_[F], ms_[F], T_[17];                                                     \
+        const bool changed_ = (M).changed;                                                  \
+        feature_slots<N>(pack_board((M).after), s_);                                        \
+        memory_slots<N>(pack_board((M).after), ms_);        /* (used for the features behind the four-cell ones) */ \
+        _Pragma("unroll") for (int f = 0; f < 17; ++f) T_[f] = bit_transpose16(s_[f] & 0xFFFFu); \
+        REGS(G2048_HOT_LDS)                                                                 \
+        asm volatile("s_waitcnt lgkmcnt(0)");       /* the LDS words are in before a global load may land on top of them */ \
+        REGS(G2048_HOT_GLB)                                                                 \
+        _Pragma("unroll") for (int f = 17; f < F; ++f) XC[f - 17] = ld_w(w, changed_ ? ms_[f] : 0u); \
     }
-    /* The masked load is inline asm: as C, the compiler merges "loaded" and "not loaded" at the end of the branch and waits  \
-       for the load right there (84 gathers going out one at a time).  It therefore does not know that X[f] is in flight:       \
-       G2048_HOT_FENCE below waits for the memory queue and names every X[f], so that no use can be scheduled above it. */       \
-#define G2048_HOT_B(M, X, T, MS)                                                            \
-    _Pragma("unroll") for (int f = 0; f < 17; ++f)                                          \
-        if ((M).changed && T[f] >= HOT_PER_FEATURE) {                                       \
-            const uint32_t off_ = ((uint32_t)f * 65536u + T[f]) << 2;                       \
-            asm volatile("global_load_dword %0, %1, %2" : "+v"(X[f]) : "v"(off_), "s"(w)); \
-        }                                                                                   \
-    _Pragma("unroll") for (int f = 17; f < F; ++f) X[f] = ld_w(w, (M).changed ? MS[f] : 0u);
-#define G2048_HOT_FENCE(X)                                                                  \
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(X[0]), "+v"(X[1]), "+v"(X[2]), "+v"(X[3]), "+v"(X[4]), "+v"(X[5]), "+v"(X[6]), "+v"(X[7]), "+v"(X[8]), \
-                 "+v"(X[9]), "+v"(X[10]), "+v"(X[11]), "+v"(X[12]), "+v"(X[13]), "+v"(X[14]), "+v"(X[15]), "+v"(X[16]));
-    if constexpr (F <= G2048_BATCH4_MAXF) {
-        G2048_HOT_A(mv.m0, x0, t0, q0)
-        G2048_HOT_B(mv.m0, x0, t0, q0)
-        G2048_HOT_A(mv.m1, x1, t1, q1)
-        G2048_HOT_B(mv.m1, x1, t1, q1)
-        G2048_HOT_A(mv.m2, x2, t2, q2)
-        G2048_HOT_B(mv.m2, x2, t2, q2)
-        G2048_HOT_A(mv.m3, x3, t3, q3)
-        G2048_HOT_B(mv.m3, x3, t3, q3)
-        G2048_HOT_FENCE(x0) G2048_HOT_FENCE(x1) G2048_HOT_FENCE(x2) G2048_HOT_FENCE(x3)
-        float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f, v3 = 0.0f;      // each a left-to-right sum, as QAgent.evaluate
-#pragma unroll
-        for (int f = 0; f < F; ++f) {
-            v0 += x0[f];
-            v1 += x1[f];
-            v2 += x2[f];
-            v3 += x3[f];
-        }
-        c.v[0] = mv.m0.changed ? v0 : -INFINITY;
-        c.v[1] = mv.m1.changed ? v1 : -INFINITY;
-        c.v[2] = mv.m2.changed ? v2 : -INFINITY;
-        c.v[3] = mv.m3.changed ? v3 : -INFINITY;
-    } else {
-        {
-            G2048_HOT_A(mv.m0, x0, t0, q0)
-            G2048_HOT_B(mv.m0, x0, t0, q0)
-            G2048_HOT_A(mv.m1, x1, t1, q1)
-            G2048_HOT_B(mv.m1, x1, t1, q1)
-            G2048_HOT_FENCE(x0) G2048_HOT_FENCE(x1)
-            float v0 = 0.0f, v1 = 0.0f;
-#pragma unroll
-            for (int f = 0; f < F; ++f) {
-                v0 += x0[f];
-                v1 += x1[f];
-            }
-            c.v[0] = mv.m0.changed ? v0 : -INFINITY;
-            c.v[1] = mv.m1.changed ? v1 : -INFINITY;
-        }
-        {
-            G2048_HOT_A(mv.m2, x2, t2, q2)
-            G2048_HOT_B(mv.m2, x2, t2, q2)
-            G2048_HOT_A(mv.m3, x3, t3, q3)
-            G2048_HOT_B(mv.m3, x3, t3, q3)
-            G2048_HOT_FENCE(x2) G2048_HOT_FENCE(x3)
-            float v2 = 0.0f, v3 = 0.0f;
-#pragma unroll
-            for (int f = 0; f < F; ++f) {
-                v2 += x2[f];
-                v3 += x3[f];
-            }
-            c.v[2] = mv.m2.changed ? v2 : -INFINITY;
-            c.v[3] = mv.m3.changed ? v3 : -INFINITY;
-        }
+#define G2048_HOT_ADD(f, reg) asm volatile("v_add_f32 %0, %0, " reg : "+v"(acc_));
+#define G2048_HOT_SUM(REGS, XC, V)          /* a left-to-right sum from 0, as QAgent.evaluate */ \
+    float V;                                                                                \
+    {                                                                                       \
+        float acc_ = 0.0f;                                                                  \
+        REGS(G2048_HOT_ADD)                                                                 \
+        _Pragma("unroll") for (int f = 17; f < F; ++f) acc_ += XC[f - 17];                 \
+        V = acc_;                                                                           \
     }
-#undef G2048_HOT_A
-#undef G2048_HOT_B
-#undef G2048_HOT_FENCE
+    G2048_HOT_DIR(mv.m0, G2048_HOT_REGS0, xc0)
+    G2048_HOT_DIR(mv.m1, G2048_HOT_REGS1, xc1)
+    G2048_HOT_DIR(mv.m2, G2048_HOT_REGS2, xc2)
+    G2048_HOT_DIR(mv.m3, G2048_HOT_REGS3, xc3)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    G2048_HOT_SUM(G2048_HOT_REGS0, xc0, v0)
+    G2048_HOT_SUM(G2048_HOT_REGS1, xc1, v1)
+    G2048_HOT_SUM(G2048_HOT_REGS2, xc2, v2)
+    G2048_HOT_SUM(G2048_HOT_REGS3, xc3, v3)
+    c.v[0] = mv.m0.changed ? v0 : -INFINITY;
+    c.v[1] = mv.m1.changed ? v1 : -INFINITY;
+    c.v[2] = mv.m2.changed ? v2 : -INFINITY;
+    c.v[3] = mv.m3.changed ? v3 : -INFINITY;
+#undef G2048_HOT_LDS
+#undef G2048_HOT_GLB
+#undef G2048_HOT_DIR
+#undef G2048_HOT_ADD
+#undef G2048_HOT_SUM
     const bool ch[4] = {mv.m0.changed, mv.m1.changed, mv.m2.changed, mv.m3.changed};
 #pragma unroll
     for (int d = 0; d < 4; ++d)
@@ -821,9 +802,9 @@ __device__ unsigned long long g_wave_info[8192 * 4 * 2];      // per wave: end s
 #define G2048_PLAY_MIN_WAVES 0
 #endif
 template <int N, int TPB, bool HOT, bool PERM>
-__global__ __launch_bounds__(TPB, G2048_PLAY_MIN_WAVES) void k_td_play(LaneSet in, LaneSet out, const uint32_t* __restrict__ perm_, uint4* prev_nxt,
-                                                 uint32_t B, const float* __restrict__ w, float alpha, TdRecs recs, int auto_reset,
-                                                 Stats* stats, GameLog lg, uint32_t static_rounds) {
+__device__ __forceinline__ void td_play_body(LaneSet in, LaneSet out, const uint32_t* __restrict__ perm_, uint4* prev_nxt,
+                                             uint32_t B, const float* __restrict__ w, float alpha, TdRecs recs, int auto_reset,
+                                             Stats* stats, GameLog lg, uint32_t static_rounds) {
     constexpr float F = (float)Shape<N>::F;
     const uint32_t* const perm = PERM ? perm_ : nullptr;       // (compile-time: a run-time test would put a wait behind every block's first load)
     __shared__ WgStats ws;
@@ -1101,6 +1082,21 @@ __global__ __launch_bounds__(TPB, G2048_PLAY_MIN_WAVES) void k_td_play(LaneSet i
 #endif
 }
 
+// The two kernels around the body.  The hot-set form is compiled with a capped register allocator: the VGPRs above the cap
+// hold its gathers' results and are named only in choose_hot's asm statements (see there).
+template <int N, int TPB, bool PERM>
+__global__ __launch_bounds__(TPB, G2048_PLAY_MIN_WAVES) void k_td_play(LaneSet in, LaneSet out, const uint32_t* __restrict__ perm, uint4* prev_nxt, uint32_t B,
+                                                                       const float* __restrict__ w, float alpha, TdRecs recs, int auto_reset, Stats* stats,
+                                                                       GameLog lg, uint32_t static_rounds) {
+    td_play_body<N, TPB, false, PERM>(in, out, perm, prev_nxt, B, w, alpha, recs, auto_reset, stats, lg, static_rounds);
+}
+template <int N, int TPB, bool PERM>
+__global__ __launch_bounds__(TPB, G2048_PLAY_MIN_WAVES) __attribute__((amdgpu_num_vgpr(PLAY_HOT_COMPILER_VGPRS))) void k_td_play_hot(
+    LaneSet in, LaneSet out, const uint32_t* __restrict__ perm, uint4* prev_nxt, uint32_t B, const float* __restrict__ w, float alpha, TdRecs recs,
+    int auto_reset, Stats* stats, GameLog lg, uint32_t static_rounds) {
+    td_play_body<N, TPB, true, PERM>(in, out, perm, prev_nxt, B, w, alpha, recs, auto_reset, stats, lg, static_rounds);
+}
+
 // Step part 2, global-atomics form — QAgent.update for every record: thread t adds image (t & 7) of record (t >> 3);
 // records B .. B + qcount - 1 are the terminal queue.
 template <int N>
@@ -1212,8 +1208,9 @@ template <int FC> struct OwnUnroll { static constexpr int U = FC == 1 ? 4 : 1; }
 
 // variant v of table N covers features [f0(v), f0(v) + fc(v)); n >= 4: the orbit representatives ORBIT_REPS
 template <int N> struct OwnVariants { static constexpr int COUNT = N == 4 ? 5 : 6; static constexpr int f0(int v) { return ORBIT_REPS[v]; } static constexpr int fc(int) { return 1; } };
+// n = 2, 3: a variant is a chunk of PER_CHUNK whole orbit tables (n = 2: all four, 1 024 slots; n = 3: 4 x 4 096 fixed-point slots = 128 KiB, two chunks)
 template <> struct OwnVariants<2> { static constexpr int COUNT = 1; static constexpr int f0(int) { return 0; } static constexpr int fc(int) { return 24; } };
-template <> struct OwnVariants<3> { static constexpr int COUNT = 13; static constexpr int f0(int v) { return 4 * v; } static constexpr int fc(int) { return 4; } };   // 4 x 4096 fixed-point slots = 128 KiB
+template <> struct OwnVariants<3> { static constexpr int COUNT = 2; static constexpr int f0(int) { return 0; } static constexpr int fc(int) { return 52; } };
 
 #ifndef G2048_FIXED_VARIANTS
 #define G2048_FIXED_VARIANTS 6      // (5 = the cross orbit in fp32: half as many, twice as large chunks, but ds_add_f32 is 12x slower than ds_add_u64)
@@ -1286,6 +1283,28 @@ __device__ __forceinline__ void own_accum(const Packed& p, float dw, bool valid,
     }
 }
 
+// n = 2, 3: chunk V holds the orbit tables [V * PER_CHUNK, (V + 1) * PER_CHUNK) whole, so every add of those orbits is a hit;
+// one image per coset of each representative's stabiliser (SmallOrbits<N>::mask), always in fixed point.
+template <int N, int V>
+__device__ __forceinline__ void own_accum_small(const Packed& p, float dw, bool valid, float* acc, uint32_t& nhit, float scale, uint32_t cbits) {
+    using SO = SmallOrbits<N>;
+    constexpr int F = Shape<N>::F, O0 = V * SO::PER_CHUNK;
+    const unsigned long long fixed = packed_add(dw, (double)scale, cbits);
+    unsigned long long* const slots = reinterpret_cast<unsigned long long*>(acc);
+#pragma unroll
+    for (uint32_t g = 0; g < 8; ++g) {
+        uint32_t s[F];
+        feature_slots<N>(d4_image(p, g), s);            // g is a constant after unrolling; what no orbit of the chunk visits is dead code
+#pragma unroll
+        for (int j = 0; j < SO::PER_CHUNK; ++j)
+            if ((SO::mask(O0 + j) >> g) & 1u) {
+                const uint32_t local = (uint32_t)j * SO::SIZE + (s[SO::rep(O0 + j)] - feature_offset(N, SO::rep(O0 + j)));
+                if (valid) atomicAdd(slots + local, fixed);
+                nhit += valid ? 1u : 0u;
+            }
+    }
+}
+
 // the same accumulation from precomputed orbit indices (k_td_play's OrbitIdx records); idx are relative to the orbit table
 template <int NI, bool FB, bool FIXED>
 __device__ __forceinline__ void own_accum_idx(const uint32_t (&idx)[NI], float dw, bool valid, float* acc, const Slice& sl, uint32_t lo_rel,
@@ -1331,7 +1350,7 @@ __device__ __forceinline__ void own_accum_idx(const uint32_t (&idx)[NI], float d
 template <int N, int V, bool FB, bool FIXED>
 __device__ __forceinline__ void own_run(float* acc, const Slice& s, const TdRecs& recs, uint32_t B, uint32_t* hits, float* D, float* Dc,
                                         uint32_t* fb_hits, float scale, uint32_t cbits) {
-    constexpr int F0 = OwnVariants<N>::f0(V), FC = OwnVariants<N>::fc(V), OWN_UNROLL = OwnUnroll<FC>::U;
+    constexpr int F0 = OwnVariants<N>::f0(V), FC = OwnVariants<N>::fc(V);
     constexpr uint32_t IMAGES = N >= 4 ? COSET_MASK[V < 6 ? V : 0] : 0xFFu;
     uint32_t nhit = 0, nhit_wave = 0;
     if constexpr (N >= 4) {
@@ -1374,6 +1393,7 @@ __device__ __forceinline__ void own_run(float* acc, const Slice& s, const TdRecs
         }
     } else {   // main records: this part's share of the lanes, OWN_UNROLL records per thread in flight; the loop bounds are
         // wave-uniform
+        constexpr int OWN_UNROLL = 2;
         constexpr uint32_t BLK = OWN_WG * OWN_UNROLL;
         const uint32_t nblk = (B + BLK - 1) / BLK, end = B;
         for (uint32_t blk = s.part; blk < nblk; blk += s.nparts) {
@@ -1390,8 +1410,7 @@ __device__ __forceinline__ void own_run(float* acc, const Slice& s, const TdRecs
                 if (recs.unit) dw[u] = dw[u] != 0.0f ? 1.0f : 0.0f;
             }
 #pragma unroll
-            for (int u = 0; u < OWN_UNROLL; ++u)
-                own_accum<N, F0, FC, FB, FIXED, IMAGES>(unpack4(st[u]), dw[u], dw[u] != 0.0f, acc, s, nhit, D, Dc, fb_hits, scale, cbits);
+            for (int u = 0; u < OWN_UNROLL; ++u) own_accum_small<N, V>(unpack4(st[u]), dw[u], dw[u] != 0.0f, acc, nhit, scale, cbits);
         }
     }
     {   // terminal queue
@@ -1401,8 +1420,11 @@ __device__ __forceinline__ void own_run(float* acc, const Slice& s, const TdRecs
             const uint32_t r = base0 + threadIdx.x;
             const bool ok = r < end;
             const uint32_t rr = ok ? r : end - 1;
-            own_accum<N, F0, FC, FB, FIXED, IMAGES>(ld_packed(recs.qstate, rr), recs.unit ? 1.0f : recs.qdw[rr], ok, acc, s, nhit, D, Dc, fb_hits, scale,
-                                                    cbits);
+            if constexpr (N >= 4)
+                own_accum<N, F0, FC, FB, FIXED, IMAGES>(ld_packed(recs.qstate, rr), recs.unit ? 1.0f : recs.qdw[rr], ok, acc, s, nhit, D, Dc, fb_hits, scale,
+                                                        cbits);
+            else
+                own_accum_small<N, V>(ld_packed(recs.qstate, rr), recs.unit ? 1.0f : recs.qdw[rr], ok, acc, nhit, scale, cbits);
         }
     }
     // load statistics for the planner: one counter bump per wave
@@ -1511,7 +1533,10 @@ __device__ __forceinline__ void mirror_stats(const StatMirror& m) {
 // table_i[perm_i(k)] += v for every member i of the orbit; `dacc` (may be null) mirrors the add (g2048_delta_begin)
 __device__ __forceinline__ void add_to_members(float* w, float* dacc, const OrbitInfo& oi, uint32_t k, float v) {
     for (uint32_t m = 0; m < oi.nmem; ++m) {
-        const uint32_t slot = oi.radix == 16u ? table_place(oi.off[m] + permute_digits(k, oi.perm[m], oi.digits, 16u)) : oi.off[m] + permute_hex_placed(k, oi.perm[m]);
+        // (the four- and five-cell tables of n >= 4 live in table_place order, the f_6 tables in hex_place order, n = 2, 3 in index order)
+        const uint32_t slot = oi.radix != 16u ? oi.off[m] + permute_hex_placed(k, oi.perm[m])
+                                              : oi.digits >= 4u ? table_place(oi.off[m] + permute_digits(k, oi.perm[m], oi.digits, 16u))
+                                                                : oi.off[m] + permute_digits(k, oi.perm[m], oi.digits, 16u);
         w[slot] += v;
         if (dacc) dacc[slot] += v;
     }
@@ -1611,29 +1636,6 @@ __global__ __launch_bounds__(WG) void k_apply_orbits_mean(float* w, float* dacc,
     const float v = sum / cnt;
     add_to_members(w, dacc, oi, k, v);
     if (k2 != k) add_to_members(w, dacc, oi, k2, v);
-}
-
-__global__ __launch_bounds__(WG) void k_apply_flat_mean(float* w, float* dacc, float* S, float* C, uint32_t slots) {
-    const uint32_t K = blockIdx.x * WG + threadIdx.x;
-    if (K >= slots) return;
-    const float cnt = C[K];
-    if (cnt == 0.0f) return;
-    const float v = S[K] / cnt;
-    w[K] += v;
-    if (dacc) dacc[K] += v;
-    S[K] = 0.0f;
-    C[K] = 0.0f;
-}
-
-// n = 2, 3 with delta tracking on: the owner workgroups sum into S instead of the table, and this adds S to both
-__global__ __launch_bounds__(WG) void k_apply_flat_sum(float* w, float* dacc, float* S, uint32_t slots) {
-    const uint32_t K = blockIdx.x * WG + threadIdx.x;
-    if (K >= slots) return;
-    const float v = S[K];
-    if (v == 0.0f) return;
-    w[K] += v;
-    dacc[K] += v;
-    S[K] = 0.0f;
 }
 
 // n = 6: the twelve 14^6-slot tables (361 MB) do not fit in LDS, so their adds end as global atomics — but (1) through
@@ -1949,6 +1951,9 @@ __global__ __launch_bounds__(SORT_TPB) void k_sort_count(const uint4* boards, ui
         key[u] = 0;
         rank[u] = 0;
         if (i < B) {
+            // (one returning LDS atomic per lane.  Folding the lanes of a wave that share a key into one atomic first — a
+            // readlane loop over the wave's distinct keys — was measured slower, 51 against 28 us: mid-game boards put
+            // dozens of different keys into a wave)
             key[u] = sort_key(ld_board(boards, i), thr);
             const uint32_t sh = 16u * (key[u] & 1u);
             rank[u] = (atomicAdd(&tab[key[u] >> 1], 1u << sh) >> sh) & 0xFFFFu;      // (<= 4 096 per half: no carry between the halves)
@@ -1977,18 +1982,19 @@ __global__ __launch_bounds__(SORT_TPB) void k_sort_count(const uint4* boards, ui
     }
 }
 
-// start[k] = number of lanes with a smaller key; cnt is left zeroed for the next sort
+// start[k] = number of lanes with a smaller key; cnt is left zeroed for the next sort.  One workgroup, thread t owns the 64
+// consecutive buckets [64 t, 64 t + 64): a pass that only sums them (16 independent 16-byte loads), a scan of the 1 024
+// sums, and a second pass over the same 256 KB (from L2) that writes the starts.  (A row-wise form — 64 coalesced rows
+// per wave, a wave scan per row — was a chain of 64 x 6 dependent cross-lane shuffles: 57 us.)
 __global__ __launch_bounds__(SORT_TPB) void k_sort_scan(uint32_t* cnt, uint32_t* start) {
-    constexpr uint32_t PER = SORT_KEYS / SORT_TPB;          // 64 consecutive buckets per thread
+    constexpr uint32_t PER = SORT_KEYS / SORT_TPB, VEC = PER / 4;
     __shared__ uint32_t wave_sum[SORT_TPB / 64];
     uint4* const mine = reinterpret_cast<uint4*>(cnt + threadIdx.x * PER);
-    uint4 v[PER / 4];
     uint32_t sum = 0;
 #pragma unroll
-    for (uint32_t j = 0; j < PER / 4; ++j) {
-        v[j] = mine[j];
-        sum += v[j].x + v[j].y + v[j].z + v[j].w;
-        mine[j] = make_uint4(0, 0, 0, 0);
+    for (uint32_t j = 0; j < VEC; ++j) {
+        const uint4 v = mine[j];
+        sum += v.x + v.y + v.z + v.w;
     }
     uint32_t incl = sum;                                    // inclusive scan of the threads' sums: inside the wave, then over the 16 waves
 #pragma unroll
@@ -2002,13 +2008,20 @@ __global__ __launch_bounds__(SORT_TPB) void k_sort_scan(uint32_t* cnt, uint32_t*
     for (uint32_t wv = 0; wv < (threadIdx.x >> 6); ++wv) base += wave_sum[wv];
     uint4* const out = reinterpret_cast<uint4*>(start + threadIdx.x * PER);
 #pragma unroll
-    for (uint32_t j = 0; j < PER / 4; ++j) {
-        uint4 o;
-        o.x = base; base += v[j].x;
-        o.y = base; base += v[j].y;
-        o.z = base; base += v[j].z;
-        o.w = base; base += v[j].w;
-        out[j] = o;
+    for (uint32_t q = 0; q < VEC; q += 4) {
+        uint4 v[4];
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) v[j] = mine[q + j];
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) {
+            uint4 o;
+            o.x = base; base += v[j].x;
+            o.y = base; base += v[j].y;
+            o.z = base; base += v[j].z;
+            o.w = base; base += v[j].w;
+            out[q + j] = o;
+            mine[q + j] = make_uint4(0, 0, 0, 0);
+        }
     }
 }
 
@@ -2473,7 +2486,7 @@ int find_orbits(g2048_ctx* c) {
     T.total = 0;
     std::vector<int> rep_of;
     for (int i = 0; i < NF; ++i) {
-        const uint32_t nd = i < 17 ? 4u : (i < 21 ? 5u : 6u), radix = i < 21 ? 16u : 14u;
+        const uint32_t nd = N < 4 ? (uint32_t)N : i < 17 ? 4u : (i < 21 ? 5u : 6u), radix = (N < 4 || i < 21) ? 16u : 14u;
         uint32_t mine[NB][6];
         for (int t = 0; t < NB; ++t) digits_of(host_feature_index<N>(boards[t], i), radix, nd, mine[t]);
         bool placed = false;
@@ -2530,7 +2543,12 @@ int find_orbits(g2048_ctx* c) {
         oi.nstab = 1;
         oi.sperm[0] = oi.perm[0];                                   // identity
         uint32_t mask;
-        if (oi.radix == 16u) {
+        if constexpr (N < 4) {
+            using SO = SmallOrbits<N < 4 ? N : 2>;
+            if ((int)T.count != SO::COUNT || rep_of[o] != SO::rep((int)o) || oi.size != SO::SIZE) return fail(c, G2048_ERR_STATE, "unexpected orbit structure");
+            c->owned_total = oi.base + oi.size;
+            mask = SO::mask((int)o);
+        } else if (oi.radix == 16u) {
             if (o >= 6 || rep_of[o] != ORBIT_REPS[o]) return fail(c, G2048_ERR_STATE, "unexpected orbit structure");
             c->owned_total = oi.base + oi.size;
             mask = COSET_MASK[o];
@@ -2604,10 +2622,11 @@ bool chunk_fixed(const g2048_ctx* c, int variant) { return own_fixed(c->n, varia
 
 std::vector<ChunkInfo> table_chunks(const g2048_ctx* c) {
     std::vector<ChunkInfo> v;
-    if (c->n == 2) {
-        v.push_back({0, 0, Shape<2>::SLOTS, 0, 6.0, 0, 0, 0, 1});
-    } else if (c->n == 3) {
-        for (uint32_t g = 0; g < 13; ++g) v.push_back({g, g * 4u * 4096u, 4u * 4096u, g * 4u * 4096u, 3.0, 0, 0, g, 1});
+    if (c->n == 2) {            // all four orbit tables in one chunk
+        v.push_back({0, 0, c->orbits.total, 0, 3.0, 0, 0, 0, 1});
+    } else if (c->n == 3) {     // four orbit tables (4 x 4 096 fixed-point slots = 128 KiB) per chunk
+        const uint32_t csz = SmallOrbits<3>::PER_CHUNK * SmallOrbits<3>::SIZE;
+        for (uint32_t g = 0; g * csz < c->orbits.total; ++g) v.push_back({g, g * csz, csz, g * csz, 3.0, 0, 0, g, 1});
     } else if (c->n >= 4) {
         for (uint32_t o = 0; o < c->orbits.count; ++o) {
             const OrbitInfo& oi = c->orbits.o[o];
@@ -2628,8 +2647,8 @@ std::vector<ChunkInfo> table_chunks(const g2048_ctx* c) {
 int build_slices(g2048_ctx* c) {
     if (c->n == 0) return G2048_OK;
     if (!c->slices) {       // first call: orbits, device buffers, and a prior for the load
-        if (c->n >= 4) {
-            int rc = c->n == 4 ? find_orbits<4>(c) : c->n == 5 ? find_orbits<5>(c) : find_orbits<6>(c);
+        {
+            int rc = c->n == 2 ? find_orbits<2>(c) : c->n == 3 ? find_orbits<3>(c) : c->n == 4 ? find_orbits<4>(c) : c->n == 5 ? find_orbits<5>(c) : find_orbits<6>(c);
             if (rc) return rc;
             if ((rc = dalloc(c, &c->D, c->orbits.total))) return rc;
             HIP_TRY(c, hipMemset(c->D, 0, (size_t)c->orbits.total * 4));
@@ -2674,7 +2693,7 @@ int build_slices(g2048_ctx* c) {
                 const uint32_t per16 = 65536u / chunks[k].size;       // chunks per value of the cross's leading nibble
                 share = chunks[k].scan == 1.0 ? (rel == 0 ? 0.7 : rel == 1 ? 0.28 : 0.01) : (rel % per16 == 0 && rel < 8 * per16 ? 0.12 : 0.001);
             }
-            c->load[k] = 8.0 * c->B * share * (c->n == 2 ? 24 : c->n == 3 ? (chunks[k].size / 4096.0) : 1);
+            c->load[k] = 8.0 * c->B * share * (c->n == 2 ? 3 : c->n == 3 ? 3.25 : 1);      // (n = 2, 3: 24 / 26 adds per record and chunk)
         }
     }
     const double add_cost = c->knob.add_cost, thr = c->knob.thr, fixed_ratio = c->knob.fixed_ratio;
@@ -2919,7 +2938,12 @@ template <int N, int TPB, bool HOT>
 unsigned play_grid(g2048_ctx* c) {
     if (!c->play_wgs) {
         int per_cu = 0, cus = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_td_play<N, TPB, HOT, false>, TPB, 0) != hipSuccess || per_cu <= 0) per_cu = HOT ? 1 : 2;
+        hipError_t e;
+        if constexpr (HOT)
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_td_play_hot<N, TPB, false>, TPB, 0);
+        else
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_td_play<N, TPB, false>, TPB, 0);
+        if (e != hipSuccess || per_cu <= 0) per_cu = HOT ? 1 : 2;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || cus <= 0) cus = 256;
         c->play_wgs = (unsigned)(per_cu * cus);
         if (c->knob.play_wgs) c->play_wgs = c->knob.play_wgs;                                 // (experiments)
@@ -2935,9 +2959,11 @@ uint32_t play_static_rounds(const g2048_ctx* c, unsigned grid, unsigned tpb) {
 }
 
 // the LDS hot set pays once a workgroup has enough lanes to amortise its 88 KB copy; n >= 4 only
-// (n = 6: only when asked for with G2048_PLAY_HOT=2 — its four-cell gathers are 68 of 132 and go out in two batches of two
-// directions; measured +3 % for a fresh agent and -6 % for a trained one)
-bool play_hot(const g2048_ctx* c) { return c->n >= 4 && (c->n <= 5 ? c->knob.play_hot >= 1 : c->knob.play_hot >= 2) && c->B >= c->knob.play_hot_min; }
+// (n = 4, 5 only.  Round 2 also built the n = 6 form behind G2048_PLAY_HOT=2: 68 of its 132 gathers are four-cell ones and go out
+// in two batches of two directions; +3 % for a fresh agent, -6 % for a trained one, and it compiled to 256 VGPRs + 12 bytes of
+// scratch — a spill between a hot gather's inline-asm load and its fence is exactly what that path must never have
+// (tools/check_codeobj.py enforces it at build time), so the variant is gone.)
+bool play_hot(const g2048_ctx* c) { return (c->n == 4 || c->n == 5) && c->knob.play_hot >= 1 && c->B >= c->knob.play_hot_min; }
 
 // One TD step on the context's stream: k_td_play, then the update in the selected mode.  `ev` (optional) gets an
 // event between the two parts.
@@ -2985,18 +3011,17 @@ int launch_td_step(g2048_ctx* c, float alpha, hipEvent_t ev = nullptr, hipEvent_
             }
         }
     }
-#define G2048_PLAY_(NN, TPB, HOT, PERM)                                                                                               \
-    k_td_play<NN, TPB, HOT, PERM><<<play_grid<NN, TPB, HOT>(c), TPB, 0, c->stream>>>(lin, lout, perm, pn, B, c->w, alpha, recs, c->auto_reset, c->stats, c->log, \
-                                                                                      play_static_rounds(c, play_grid<NN, TPB, HOT>(c), TPB))
-#define G2048_PLAY(NN, TPB, HOT) (perm ? (G2048_PLAY_(NN, TPB, HOT, true)) : (G2048_PLAY_(NN, TPB, HOT, false)))
+#define G2048_PLAY_(KERNEL, NN, TPB, HOT, PERM)                                                                                      \
+    KERNEL<NN, TPB, PERM><<<play_grid<NN, TPB, HOT>(c), TPB, 0, c->stream>>>(lin, lout, perm, pn, B, c->w, alpha, recs, c->auto_reset, c->stats, c->log, \
+                                                                              play_static_rounds(c, play_grid<NN, TPB, HOT>(c), TPB))
+#define G2048_PLAY(KERNEL, NN, TPB, HOT) (perm ? (G2048_PLAY_(KERNEL, NN, TPB, HOT, true)) : (G2048_PLAY_(KERNEL, NN, TPB, HOT, false)))
     if (play_hot(c)) {
         switch (c->n) {
-            case 4: G2048_PLAY(4, PLAY_HOT_WG, true); break;
-            case 5: G2048_PLAY(5, PLAY_HOT_WG, true); break;
-            default: G2048_PLAY(6, PLAY_HOT_WG, true); break;
+            case 4: G2048_PLAY(k_td_play_hot, 4, PLAY_HOT_WG, true); break;
+            default: G2048_PLAY(k_td_play_hot, 5, PLAY_HOT_WG, true); break;
         }
     } else {
-        BY_N(c, (G2048_PLAY(N, 256, false)));
+        BY_N(c, (G2048_PLAY(k_td_play, N, 256, false)));
     }
 #undef G2048_PLAY
 #undef G2048_PLAY_
@@ -3019,8 +3044,8 @@ int launch_td_step(g2048_ctx* c, float alpha, hipEvent_t ev = nullptr, hipEvent_
         ++c->steps_since_read;
         const uint32_t tail_grid = B >= (1u << 16) ? 512 : 16;
         recs.unit = 0;
-        // n >= 4: the LDS-owned orbit tables are double-buffered (k_apply_orbits clears the other one for the next step)
-        const bool alt = c->n >= 4 && c->dpar;
+        // the LDS-owned orbit tables are double-buffered (k_apply_orbits clears the other one for the next step)
+        const bool alt = c->dpar;
         float* Dcur = alt ? c->D2 : c->D;
         float* Doth = alt ? c->D : c->D2;
         float* Ccur = alt ? c->Dcnt2 : c->Dcnt;
@@ -3042,10 +3067,8 @@ int launch_td_step(g2048_ctx* c, float alpha, hipEvent_t ev = nullptr, hipEvent_
             if (!one_pass) BY_N(c, (k_td_update_owner<N><<<c->n_slices, OWN_WG, 0, c->stream>>>(Ccur, nullptr, ones, B, c->slices, c->hits, c->wg_clock)));
             if (c->n == 6 && !hex_binned) k_td_update_tail<6><<<tail_grid, OWN_WG, 0, c->stream>>>(c->Dcnt, ones, B, c->orbits.o[6].base, c->orbits.o[7].base);
         }
-        // n = 2, 3: the workgroups add straight into the table, unless the sums are needed apart (mean rule, delta tracking)
-        const bool flat_apart = c->n < 4 && (c->update_rule == 1 || dacc);
-        float* dst = c->n >= 4 ? Dcur : (flat_apart ? c->D : c->w);
-        float* cdst = one_pass ? (c->n >= 4 ? Ccur : c->Dcnt) : nullptr;
+        float* dst = Dcur;
+        float* cdst = one_pass ? Ccur : nullptr;
         BY_N(c, (k_td_update_owner<N><<<c->n_slices, OWN_WG, 0, c->stream>>>(dst, cdst, recs, B, c->slices, c->hits, c->wg_clock)));
         if (ev_owner) (void)hipEventRecord(ev_owner, c->stream);
         if (hex_binned) {           // the f_6 orbits: bin the (slot, dw) pairs by table chunk, then LDS owners (k_hex_*)
@@ -3063,21 +3086,15 @@ int launch_td_step(g2048_ctx* c, float alpha, hipEvent_t ev = nullptr, hipEvent_
                             (uint32_t)(STAT_BYTES / 4)};
         OrbitTable ot = c->orbits;
         if (hex_binned) ot.total = c->owned_total;      // the f_6 orbit tables are applied chunk by chunk (k_hex_apply)
-        if (c->update_rule == 1) {
-            if (c->n >= 4)
-                k_apply_orbits_mean<<<grid_for(ot.total), WG, 0, c->stream>>>(c->w, dacc, c->D, c->Dcnt, Dcur, Ccur, Doth, Coth, c->owned_total, ot, sm);
-            else
-                k_apply_flat_mean<<<grid_for(c->slots), WG, 0, c->stream>>>(c->w, dacc, c->D, c->Dcnt, (uint32_t)c->slots);
-        } else if (c->n >= 4) {
+        if (c->update_rule == 1)
+            k_apply_orbits_mean<<<grid_for(ot.total), WG, 0, c->stream>>>(c->w, dacc, c->D, c->Dcnt, Dcur, Ccur, Doth, Coth, c->owned_total, ot, sm);
+        else
             k_apply_orbits<<<grid_for(ot.total), WG, 0, c->stream>>>(c->w, dacc, c->D, Dcur, Doth, c->owned_total, ot, sm);
-        } else if (flat_apart) {
-            k_apply_flat_sum<<<grid_for(c->slots), WG, 0, c->stream>>>(c->w, dacc, c->D, (uint32_t)c->slots);
-        }
         if (hex_binned) {
             const uint32_t hb = c->orbits.o[6].base;
             k_hex_apply<<<grid_for(HEX_SLOTS), WG, 0, c->stream>>>(c->w, dacc, c->D + hb, c->update_rule == 1 ? c->Dcnt + hb : nullptr, c->hex, c->orbits.o[6], c->orbits.o[7]);
         }
-        if (c->n >= 4) c->dpar ^= 1u;
+        c->dpar ^= 1u;
     } else {
         BY_N(c, (k_td_update<N><<<grid_for((uint64_t)B * 16), WG, 0, c->stream>>>(c->w, c->tracking && c->knob.delta_accum ? c->delta : nullptr, recs, B)));
         if (ev_owner) (void)hipEventRecord(ev_owner, c->stream);
@@ -3625,7 +3642,7 @@ int g2048_set_update_rule(g2048_ctx* c, int rule) {
     if (rule == 1) {
         NEED(c, c->update_mode == 1, "the per-slot mean rule needs the LDS-owner update (update mode 1)");
         if (int rc = bind(c)) return rc;
-        const size_t count = c->n >= 4 ? c->orbits.total : c->slots;
+        const size_t count = c->orbits.total;
         int rc;
         if (!c->D) {
             if ((rc = dalloc(c, &c->D, count))) return rc;
@@ -3635,11 +3652,11 @@ int g2048_set_update_rule(g2048_ctx* c, int rule) {
             if ((rc = dalloc(c, &c->Dcnt, count))) return rc;
             HIP_TRY(c, hipMemset(c->Dcnt, 0, count * 4));
         }
-        if (c->n >= 4 && !c->Dcnt2) {
+        if (!c->Dcnt2) {
             if ((rc = dalloc(c, &c->Dcnt2, c->owned_total))) return rc;
             HIP_TRY(c, hipMemset(c->Dcnt2, 0, (size_t)c->owned_total * 4));
         }
-        if (c->n >= 4 && c->update_rule == 0) {     // steps under the sum rule leave the count buffers alone: start clean
+        if (c->update_rule == 0) {     // steps under the sum rule leave the count buffers alone: start clean
             HIP_TRY(c, hipMemsetAsync(c->Dcnt, 0, (size_t)c->owned_total * 4, c->stream));
             HIP_TRY(c, hipMemsetAsync(c->Dcnt2, 0, (size_t)c->owned_total * 4, c->stream));
         }
@@ -3829,10 +3846,6 @@ static int ensure_delta(g2048_ctx* c) {
     if (!c->delta) {
         if ((rc = dalloc(c, &c->delta, c->slots))) return rc;
         HIP_TRY(c, hipMemsetAsync(c->delta, 0, c->slots * 4, c->stream));
-    }
-    if (c->n < 4 && !c->D) {            // n = 2, 3: the owner workgroups then sum into D instead of the table (k_apply_flat_sum)
-        if ((rc = dalloc(c, &c->D, c->slots))) return rc;
-        HIP_TRY(c, hipMemsetAsync(c->D, 0, c->slots * 4, c->stream));
     }
     return G2048_OK;
 }

@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""Build-time guard of the contract the LDS-hot-set gathers of k_td_play rest on (g2048.hip, G2048_HOT_B / G2048_HOT_FENCE).
+
+Those gathers are `global_load_dword` instructions issued from inline asm into registers the compiler believes are already
+valid; one `s_waitcnt vmcnt(0)` (the fence) stands before their first use.  That is only correct while the compiler neither
+spills nor copies nor reuses such a register between the load and the fence.  __graft_entry__.build() runs this script on
+the shipped lib2048_hip.so and FAILS the build if, in any k_td_play<*, *, HOT = true, *>:
+
+  1. the kernel has scratch (private_segment_fixed_size > 0) or spilled VGPRs — a spill is how an in-flight value gets saved;
+  2. between a global_load_dword and the first s_waitcnt that guarantees its completion (vmcnt retires in order: the load is
+     done once vmcnt <= the number of vector-memory instructions issued after it), any instruction reads or writes the
+     load's destination register.  The rule holds for compiler-scheduled loads as well (the compiler obeys it by
+     construction), so every load of the kernel is checked, not only the asm ones.
+
+It also prints registers / scratch / LDS of every kernel with scratch, for the record.
+
+    python tools/check_codeobj.py [path/to/lib2048_hip.so]
+"""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+LLVM = '/opt/rocm/lib/llvm/bin'
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TARGET = 'hipv4-amdgcn-amd-amdhsa--gfx950'
+
+
+def extract_code_object(so, workdir):
+    fat, co = os.path.join(workdir, 'fatbin'), os.path.join(workdir, 'code.co')
+    subprocess.check_call([f'{LLVM}/llvm-objcopy', '--dump-section', f'.hip_fatbin={fat}', so, os.path.join(workdir, 'copy.so')])
+    subprocess.check_call([f'{LLVM}/clang-offload-bundler', '--unbundle', '--type=o', f'--input={fat}', f'--targets={TARGET}', f'--output={co}'])
+    return co
+
+
+def kernel_notes(co):
+    """{symbol: {vgpr_count, private_segment_fixed_size, vgpr_spill_count, sgpr_spill_count, group_segment_fixed_size}}"""
+    text = subprocess.check_output([f'{LLVM}/llvm-readelf', '--notes', co], text=True)
+    out, cur = {}, None
+    for block in re.split(r'\n  - \.agpr_count:', text):
+        name = re.search(r'\.name:\s+(\S+)', block)
+        if not name:
+            continue
+        cur = {}
+        for key in ('vgpr_count', 'private_segment_fixed_size', 'vgpr_spill_count', 'sgpr_spill_count', 'group_segment_fixed_size'):
+            m = re.search(r'\.' + key + r':\s+(\d+)', block)
+            cur[key] = int(m.group(1)) if m else -1
+        out[name.group(1)] = cur
+    return out
+
+
+def disassemble(co, symbol):
+    """[(address, text, branch target address or None)] of one kernel."""
+    text = subprocess.check_output([f'{LLVM}/llvm-objdump', '-d', f'--disassemble-symbols={symbol}', co], text=True)
+    ins, base = [], None
+    for line in text.splitlines():
+        m = re.match(r'^([0-9a-f]+) <', line)
+        if m:
+            base = int(m.group(1), 16)
+            continue
+        m = re.match(r'^\s+(\S.*?)\s*//\s*([0-9A-Fa-f]+):', line)
+        if not m:
+            continue
+        target = None
+        t = re.search(r'<[^>]*\+0x([0-9a-f]+)>\s*$', line)
+        if t and m.group(1).startswith(('s_branch', 's_cbranch')):
+            target = base + int(t.group(1), 16)
+        ins.append((int(m.group(2), 16), m.group(1), target))
+    return ins
+
+
+REG = re.compile(r'\bv(\d+)\b|\bv\[(\d+):(\d+)\]')
+LOADS = ('global_load', 'flat_load', 'buffer_load', 'scratch_load')
+VMCNT_MAX = 63
+
+
+def vregs(operands):
+    regs = set()
+    for m in REG.finditer(operands):
+        if m.group(1) is not None:
+            regs.add(int(m.group(1)))
+        else:
+            regs.update(range(int(m.group(2)), int(m.group(3)) + 1))
+    return regs
+
+
+def is_load(op, rest):
+    return op.startswith(LOADS) or ('atomic' in op and op.startswith(('global_', 'flat_', 'buffer_')) and 'sc0' in rest.split())
+
+
+def check_inflight(ins):
+    """For every load: walk ALL paths of the control-flow graph from the load until an s_waitcnt that guarantees its
+    completion, and report every instruction on the way that names one of its destination registers.  Loads return in
+    order among loads (stores and loads may pass each other, so only LATER LOADS count): the load is complete at
+    `s_waitcnt vmcnt(n)` iff n <= number of loads issued after it.  Returns [(load index, offending index)]."""
+    index_of = {a: i for i, (a, _, _) in enumerate(ins)}
+    parsed = []
+    for _, text, _ in ins:
+        op, _, rest = text.partition(' ')
+        parsed.append((op, rest, vregs(rest), is_load(op, rest)))
+    bad = []
+    for li, (op, rest, _, load) in enumerate(parsed):
+        if not load:
+            continue
+        dest = vregs(rest.split(',')[0])
+        seen, work = set(), [(li + 1, 0)]
+        while work:
+            pc, later = work.pop()
+            while pc < len(ins):
+                key = (pc, min(later, VMCNT_MAX + 1))
+                if key in seen:
+                    break
+                seen.add(key)
+                op, rest, touched, load2 = parsed[pc]
+                if op.startswith('s_waitcnt'):
+                    m = re.search(r'vmcnt\((\d+)\)', rest)
+                    if m and int(m.group(1)) <= later:
+                        break                                   # complete on this path
+                    pc += 1
+                    continue
+                if dest & touched:
+                    bad.append((li, pc))
+                    break
+                if load2:
+                    later += 1
+                if op == 's_endpgm':
+                    break
+                target = ins[pc][2]
+                if target is not None:
+                    if target in index_of:
+                        work.append((index_of[target], later))
+                    if op == 's_branch':
+                        break
+                pc += 1
+    return sorted(set(bad))
+
+
+def main():
+    so = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, '2048_amd', 'lib2048_hip.so')
+    failures = []
+    with tempfile.TemporaryDirectory() as tmp:
+        co = extract_code_object(so, tmp)
+        notes = kernel_notes(co)
+        hot = [k for k in notes if re.search(r'k_td_play_hotILi\d+ELi\d+ELb[01]E', k)]
+        if not hot:
+            failures.append('no k_td_play_hot<*, *, *> kernel found in the code object (did the mangling change?)')
+        for k in sorted(notes):
+            d = notes[k]
+            if d['private_segment_fixed_size'] > 0 or d['vgpr_spill_count'] > 0:
+                short = re.sub(r'^_ZN12_GLOBAL__N_1\d+', '', k)[:60]
+                print(f'[codeobj] note: {short}: scratch {d["private_segment_fixed_size"]} B, {d["vgpr_count"]} VGPRs, {d["vgpr_spill_count"]} spilled')
+        for k in hot:
+            d = notes[k]
+            tag = re.search(r'k_td_play_hotILi(\d+)ELi(\d+)ELb([01])E', k)
+            name = f'k_td_play_hot<{tag.group(1)}, {tag.group(2)}, {"true" if tag.group(3) == "1" else "false"}>'
+            if d['private_segment_fixed_size'] != 0 or d['vgpr_spill_count'] != 0:
+                failures.append(f'{name}: scratch {d["private_segment_fixed_size"]} B, {d["vgpr_spill_count"]} spilled VGPRs — the in-flight '
+                                f'registers of the hot gathers may have been spilled')
+            ins = disassemble(co, k)
+            loads = sum(1 for _, x, _ in ins if x.startswith('global_load_dword '))
+            fences = sum(1 for _, x, _ in ins if x.startswith('s_waitcnt vmcnt(0)'))
+            bad = check_inflight(ins)
+            print(f'[codeobj] {name}: {d["vgpr_count"]} VGPRs, scratch {d["private_segment_fixed_size"]} B, LDS {d["group_segment_fixed_size"]} B, '
+                  f'{len(ins)} instructions, {loads} global_load_dword, {fences} full vmcnt fences, {len(bad)} in-flight register touches')
+            if loads < 4 * 17:
+                failures.append(f'{name}: only {loads} global_load_dword (expected >= 68 per loop copy): is the hot path still there?')
+            for li, oi in bad[:5]:
+                failures.append(f'{name}: "{ins[oi][1]}" names the destination of "{ins[li][1]}" (issued {oi - li} instructions earlier) on a path without a covering s_waitcnt')
+    if failures:
+        print('\n'.join('[codeobj] FAIL: ' + f for f in failures))
+        return 1
+    print('[codeobj] ok: no scratch in the hot-set kernels, no instruction touches a load destination before its wait')
+    return 0
+
+
+if __name__ == '__main__':
+    sys.exit(main())
