@@ -492,16 +492,31 @@ __device__ __forceinline__ Choice choose(const float* __restrict__ w, const Move
 #endif
 constexpr uint32_t HOT_PER_FEATURE = G2048_HOT_ENTRIES, HOT_FEATURES = 17u, HOT_SLOTS = HOT_FEATURES * HOT_PER_FEATURE;
 constexpr int PLAY_HOT_WG = 512;        // one workgroup per CU shares the copy (two waves per SIMD, as without it)
+// n = 2, 3 (round 3): n = 2's whole table is 24 KB and lives in LDS; n = 3 keeps the 8^3 = 512 entries of each of its 52
+// tables whose three cells are all below 8 (tiles up to 128: every gather of a young board, most of a trained agent's) — 104 KB.
+constexpr uint32_t SMALL3_PER_FEATURE = 512u;
+template <int N> struct HotShape { static constexpr uint32_t SLOTS = HOT_SLOTS; };
+template <> struct HotShape<2> { static constexpr uint32_t SLOTS = Shape<2>::SLOTS; };
+template <> struct HotShape<3> { static constexpr uint32_t SLOTS = 52u * SMALL3_PER_FEATURE; };
+// index of a three-cell table entry (a << 8 | b << 4 | c) in the LDS copy, if a, b, c < 8
+__device__ __forceinline__ uint32_t small3_index(uint32_t rel) { return ((rel >> 2) & 0x1C0u) | ((rel >> 1) & 0x38u) | (rel & 7u); }
 
 // In the table's memory order (table_place) the entries of small tiles come first: transposed index t < 256 = every cell of
 // the tuple empty / 2 / 4 / 8, t < 1 024 = 45 % of a fresh agent's gathers and 33 % of a trained agent's
 // (tools/hot_coverage.py).  So "hot" is one compare on a number the gather computes anyway and t is the LDS index.
-template <int TPB>
+template <int N, int TPB>
 __device__ __forceinline__ void load_hot_set(float* hot, const float* __restrict__ w) {
     static_assert(HOT_PER_FEATURE % 4u == 0u, "the copy moves 16 bytes per thread and turn");
-    for (uint32_t j = 4u * threadIdx.x; j < HOT_SLOTS; j += 4u * TPB) {
-        const uint32_t f = j / HOT_PER_FEATURE, t = j - f * HOT_PER_FEATURE;
-        *reinterpret_cast<float4*>(hot + j) = *reinterpret_cast<const float4*>(w + f * 65536u + t);
+    for (uint32_t j = 4u * threadIdx.x; j < HotShape<N>::SLOTS; j += 4u * TPB) {
+        if constexpr (N == 2) {
+            *reinterpret_cast<float4*>(hot + j) = *reinterpret_cast<const float4*>(w + j);
+        } else if constexpr (N == 3) {          // j = f * 512 + (a << 6 | b << 3 | c), c a multiple of 4: four consecutive table entries
+            const uint32_t f = j / SMALL3_PER_FEATURE, t = j - f * SMALL3_PER_FEATURE;
+            *reinterpret_cast<float4*>(hot + j) = *reinterpret_cast<const float4*>(w + f * 4096u + ((t >> 6) << 8 | ((t >> 3) & 7u) << 4 | (t & 7u)));
+        } else {
+            const uint32_t f = j / HOT_PER_FEATURE, t = j - f * HOT_PER_FEATURE;
+            *reinterpret_cast<float4*>(hot + j) = *reinterpret_cast<const float4*>(w + f * 65536u + t);
+        }
     }
     __syncthreads();
 }
@@ -518,18 +533,21 @@ __device__ __forceinline__ void load_hot_set(float* hot, const float* __restrict
 // ordinary variables ("+v"(x[f])): the compiler believed x[f] valid from that point on while the load was still in flight
 // until a fence further down, and was free to copy or spill it in between — tools/check_codeobj.py found it doing exactly
 // that in the shipped k_td_play<5, 512, true, true> (v_mov_b32 v209, v2 some 1 900 instructions after global_load_dword v2,
-// no wait in between: right only because the load had long returned).  Now the kernels that use this path are compiled with
-// amdgpu_num_vgpr(PLAY_HOT_COMPILER_VGPRS): the register allocator owns v0 .. v171, and v172 .. v239 are named only inside
-// the asm statements below — the LDS read, the masked global load, and, behind `s_waitcnt vmcnt(0)`, the v_add_f32 that
-// consumes each of them.  Nothing the compiler generates can touch a result in flight, by construction, and
-// tools/check_codeobj.py (run by __graft_entry__.build()) still checks the code object: no scratch, no instruction that
-// names a load's destination before a wait that covers it.
-#define G2048_HOT_REGS0(M) M(0, "v172") M(1, "v173") M(2, "v174") M(3, "v175") M(4, "v176") M(5, "v177") M(6, "v178") M(7, "v179") M(8, "v180") M(9, "v181") M(10, "v182") M(11, "v183") M(12, "v184") M(13, "v185") M(14, "v186") M(15, "v187") M(16, "v188")
-#define G2048_HOT_REGS1(M) M(0, "v189") M(1, "v190") M(2, "v191") M(3, "v192") M(4, "v193") M(5, "v194") M(6, "v195") M(7, "v196") M(8, "v197") M(9, "v198") M(10, "v199") M(11, "v200") M(12, "v201") M(13, "v202") M(14, "v203") M(15, "v204") M(16, "v205")
-#define G2048_HOT_REGS2(M) M(0, "v206") M(1, "v207") M(2, "v208") M(3, "v209") M(4, "v210") M(5, "v211") M(6, "v212") M(7, "v213") M(8, "v214") M(9, "v215") M(10, "v216") M(11, "v217") M(12, "v218") M(13, "v219") M(14, "v220") M(15, "v221") M(16, "v222")
-#define G2048_HOT_REGS3(M) M(0, "v223") M(1, "v224") M(2, "v225") M(3, "v226") M(4, "v227") M(5, "v228") M(6, "v229") M(7, "v230") M(8, "v231") M(9, "v232") M(10, "v233") M(11, "v234") M(12, "v235") M(13, "v236") M(14, "v237") M(15, "v238") M(16, "v239")
-#define PLAY_HOT_COMPILER_VGPRS 172
-#define PLAY_HOT_LAST_VGPR "v239"
+// no wait in between: right only because the load had long returned).  Now the kernels that use this path carry
+// amdgpu_waves_per_eu(3, 3): the register allocator is then held to the budget of three waves per SIMD, 512 / 3 -> 168 VGPRs
+// (v0 .. v167; it spills rather than exceed it — amdgpu_num_vgpr, the attribute made for this, is silently ignored on gfx950:
+// tools/check_codeobj.py showed the compiler at home in the "reserved" range), and v168 .. v235 are named only inside the asm
+// statements below — the LDS read, the masked global load, and, behind `s_waitcnt vmcnt(0)`, the v_add_f32 that consumes
+// each of them.  (The clobber of the last one puts them into the kernel's VGPR count; the kernel still runs two waves per
+// SIMD, one 512-thread workgroup per CU, as its LDS footprint dictates.)  Nothing the compiler generates can touch a result
+// in flight, and tools/check_codeobj.py (run by __graft_entry__.build()) checks the code object for it: no scratch, no
+// instruction that names a load's destination before a wait that covers it.
+#define G2048_HOT_REGS0(M) M(0, "v168") M(1, "v169") M(2, "v170") M(3, "v171") M(4, "v172") M(5, "v173") M(6, "v174") M(7, "v175") M(8, "v176") M(9, "v177") M(10, "v178") M(11, "v179") M(12, "v180") M(13, "v181") M(14, "v182") M(15, "v183") M(16, "v184")
+#define G2048_HOT_REGS1(M) M(0, "v185") M(1, "v186") M(2, "v187") M(3, "v188") M(4, "v189") M(5, "v190") M(6, "v191") M(7, "v192") M(8, "v193") M(9, "v194") M(10, "v195") M(11, "v196") M(12, "v197") M(13, "v198") M(14, "v199") M(15, "v200") M(16, "v201")
+#define G2048_HOT_REGS2(M) M(0, "v202") M(1, "v203") M(2, "v204") M(3, "v205") M(4, "v206") M(5, "v207") M(6, "v208") M(7, "v209") M(8, "v210") M(9, "v211") M(10, "v212") M(11, "v213") M(12, "v214") M(13, "v215") M(14, "v216") M(15, "v217") M(16, "v218")
+#define G2048_HOT_REGS3(M) M(0, "v219") M(1, "v220") M(2, "v221") M(3, "v222") M(4, "v223") M(5, "v224") M(6, "v225") M(7, "v226") M(8, "v227") M(9, "v228") M(10, "v229") M(11, "v230") M(12, "v231") M(13, "v232") M(14, "v233") M(15, "v234") M(16, "v235")
+#define PLAY_HOT_WAVES_PER_EU 3           // the allocator owns 512 / 3 -> 168 VGPRs: v0 .. v167
+#define PLAY_HOT_LAST_VGPR "v235"
 
 template <int N>
 __device__ __forceinline__ Choice choose_hot(const float* __restrict__ w, const float* hot_, const Moves4& mv) {
@@ -603,6 +621,148 @@ __device__ __forceinline__ Choice choose_hot(const float* __restrict__ w, const 
     return c;
 }
 
+// choose<N> for n = 2, 3 with the LDS copy (HotShape<N>).
+// n = 2: every gather is an LDS read.  n = 3: the two phases of choose_hot — (A) every lane reads the LDS copy, (B) the lanes
+// with a cell >= 8 overwrite the word with a global load under their exec mask — two directions (2 x 52 gathers) in flight
+// at a time, the results in VGPRs above the register allocator's range (amdgpu_waves_per_eu(4, 4): v0 .. v127 are the
+// compiler's, v128 .. v231 the gathers'; see choose_hot).
+#define G2048_S3_REGS0(M) M(0, "v128") M(1, "v129") M(2, "v130") M(3, "v131") M(4, "v132") M(5, "v133") M(6, "v134") M(7, "v135") M(8, "v136") M(9, "v137") M(10, "v138") M(11, "v139") M(12, "v140") M(13, "v141") M(14, "v142") M(15, "v143") M(16, "v144") M(17, "v145") M(18, "v146") M(19, "v147") M(20, "v148") M(21, "v149") M(22, "v150") M(23, "v151") M(24, "v152") M(25, "v153") M(26, "v154") M(27, "v155") M(28, "v156") M(29, "v157") M(30, "v158") M(31, "v159") M(32, "v160") M(33, "v161") M(34, "v162") M(35, "v163") M(36, "v164") M(37, "v165") M(38, "v166") M(39, "v167") M(40, "v168") M(41, "v169") M(42, "v170") M(43, "v171") M(44, "v172") M(45, "v173") M(46, "v174") M(47, "v175") M(48, "v176") M(49, "v177") M(50, "v178") M(51, "v179")
+#define G2048_S3_REGS1(M) M(0, "v180") M(1, "v181") M(2, "v182") M(3, "v183") M(4, "v184") M(5, "v185") M(6, "v186") M(7, "v187") M(8, "v188") M(9, "v189") M(10, "v190") M(11, "v191") M(12, "v192") M(13, "v193") M(14, "v194") M(15, "v195") M(16, "v196") M(17, "v197") M(18, "v198") M(19, "v199") M(20, "v200") M(21, "v201") M(22, "v202") M(23, "v203") M(24, "v204") M(25, "v205") M(26, "v206") M(27, "v207") M(28, "v208") M(29, "v209") M(30, "v210") M(31, "v211") M(32, "v212") M(33, "v213") M(34, "v214") M(35, "v215") M(36, "v216") M(37, "v217") M(38, "v218") M(39, "v219") M(40, "v220") M(41, "v221") M(42, "v222") M(43, "v223") M(44, "v224") M(45, "v225") M(46, "v226") M(47, "v227") M(48, "v228") M(49, "v229") M(50, "v230") M(51, "v231")
+#define PLAY_SMALL3_WAVES_PER_EU 4        // k_eval_select_lds3: the allocator owns 512 / 4 = 128 VGPRs (v0 .. v127), two directions in flight
+#define PLAY_SMALL3_LAST_VGPR "v231"
+// k_td_play_lds3 needs more than 128 registers for everything else a step does: budget of three waves (v0 .. v167), ONE
+// direction's 52 gathers in flight at a time
+#define G2048_S3P_REGS(M) M(0, "v168") M(1, "v169") M(2, "v170") M(3, "v171") M(4, "v172") M(5, "v173") M(6, "v174") M(7, "v175") M(8, "v176") M(9, "v177") M(10, "v178") M(11, "v179") M(12, "v180") M(13, "v181") M(14, "v182") M(15, "v183") M(16, "v184") M(17, "v185") M(18, "v186") M(19, "v187") M(20, "v188") M(21, "v189") M(22, "v190") M(23, "v191") M(24, "v192") M(25, "v193") M(26, "v194") M(27, "v195") M(28, "v196") M(29, "v197") M(30, "v198") M(31, "v199") M(32, "v200") M(33, "v201") M(34, "v202") M(35, "v203") M(36, "v204") M(37, "v205") M(38, "v206") M(39, "v207") M(40, "v208") M(41, "v209") M(42, "v210") M(43, "v211") M(44, "v212") M(45, "v213") M(46, "v214") M(47, "v215") M(48, "v216") M(49, "v217") M(50, "v218") M(51, "v219")
+#define PLAY_SMALL3P_WAVES_PER_EU 3
+#define PLAY_SMALL3P_LAST_VGPR "v219"
+
+template <int N, bool PAIRS = true>
+__device__ __forceinline__ Choice choose_small(const float* __restrict__ w, const float* hot_, const Moves4& mv) {
+    constexpr int F = Shape<N>::F;
+    static_assert(N == 2 || N == 3, "n = 2, 3");
+    Choice c;
+    c.action = -1;
+    c.value = -INFINITY;
+    int first_valid = -1;
+    if constexpr (N == 2) {
+        const __attribute__((address_space(3))) float* hot = (const __attribute__((address_space(3))) float*)hot_;
+        uint32_t s0[F], s1[F], s2[F], s3[F];
+        feature_slots<N>(pack_board(mv.m0.after), s0);
+        feature_slots<N>(pack_board(mv.m1.after), s1);
+        feature_slots<N>(pack_board(mv.m2.after), s2);
+        feature_slots<N>(pack_board(mv.m3.after), s3);
+        float x0[F], x1[F], x2[F], x3[F];
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            x0[f] = hot[s0[f]];
+            x1[f] = hot[s1[f]];
+            x2[f] = hot[s2[f]];
+            x3[f] = hot[s3[f]];
+        }
+        float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f, v3 = 0.0f;      // each a left-to-right sum, as QAgent.evaluate
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            v0 += x0[f];
+            v1 += x1[f];
+            v2 += x2[f];
+            v3 += x3[f];
+        }
+        c.v[0] = mv.m0.changed ? v0 : -INFINITY;
+        c.v[1] = mv.m1.changed ? v1 : -INFINITY;
+        c.v[2] = mv.m2.changed ? v2 : -INFINITY;
+        c.v[3] = mv.m3.changed ? v3 : -INFINITY;
+    } else {
+        const uint32_t hot_base = (uint32_t)(size_t)(const __attribute__((address_space(3))) float*)hot_;
+        // (counts the registers above the allocator's range into the kernel's VGPR budget)
+        if constexpr (PAIRS)
+            asm volatile("" ::: PLAY_SMALL3_LAST_VGPR);
+        else
+            asm volatile("" ::: PLAY_SMALL3P_LAST_VGPR);
+#define G2048_S3_LDS(f, reg) \
+    asm volatile("ds_read_b32 " reg ", %0" ::"v"(hot_base + (((uint32_t)(f) * SMALL3_PER_FEATURE + small3_index(s_[f] - (uint32_t)(f) * 4096u)) << 2)));
+#define G2048_S3_GLB(f, reg) \
+    if (changed_ && (s_[f] & 0x888u)) asm volatile("global_load_dword " reg ", %0, %1" ::"v"(s_[f] << 2), "s"(w));
+#define G2048_S3_DIR(M, REGS)                                                               \
+    {                                                                                       \
+        uint32_t s_[F];                                                                     \
+        const bool changed_ = (M).changed;                                                  \
+        feature_slots<N>(pack_board((M).after), s_);        /* (feature f's slots start at f * 4096: bits 3, 7, 11 are the cells' bit 3) */ \
+        REGS(G2048_S3_LDS)                                                                  \
+        asm volatile("s_waitcnt lgkmcnt(0)");       /* the LDS words are in before a global load may land on top of them */ \
+        REGS(G2048_S3_GLB)                                                                  \
+    }
+#define G2048_S3_ADD(f, reg) asm volatile("v_add_f32 %0, %0, " reg : "+v"(acc_));
+#define G2048_S3_SUM(REGS, V)               /* a left-to-right sum from 0, as QAgent.evaluate */ \
+    float V;                                                                                \
+    {                                                                                       \
+        float acc_ = 0.0f;                                                                  \
+        REGS(G2048_S3_ADD)                                                                  \
+        V = acc_;                                                                           \
+    }
+        float v0, v1, v2, v3;
+        if constexpr (PAIRS) {
+            G2048_S3_DIR(mv.m0, G2048_S3_REGS0)
+            G2048_S3_DIR(mv.m1, G2048_S3_REGS1)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            G2048_S3_SUM(G2048_S3_REGS0, a0)
+            G2048_S3_SUM(G2048_S3_REGS1, a1)
+            G2048_S3_DIR(mv.m2, G2048_S3_REGS0)
+            G2048_S3_DIR(mv.m3, G2048_S3_REGS1)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            G2048_S3_SUM(G2048_S3_REGS0, a2)
+            G2048_S3_SUM(G2048_S3_REGS1, a3)
+            v0 = a0; v1 = a1; v2 = a2; v3 = a3;
+        } else {
+            G2048_S3_DIR(mv.m0, G2048_S3P_REGS)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            G2048_S3_SUM(G2048_S3P_REGS, a0)
+            G2048_S3_DIR(mv.m1, G2048_S3P_REGS)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            G2048_S3_SUM(G2048_S3P_REGS, a1)
+            G2048_S3_DIR(mv.m2, G2048_S3P_REGS)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            G2048_S3_SUM(G2048_S3P_REGS, a2)
+            G2048_S3_DIR(mv.m3, G2048_S3P_REGS)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            G2048_S3_SUM(G2048_S3P_REGS, a3)
+            v0 = a0; v1 = a1; v2 = a2; v3 = a3;
+        }
+#undef G2048_S3_LDS
+#undef G2048_S3_GLB
+#undef G2048_S3_DIR
+#undef G2048_S3_ADD
+#undef G2048_S3_SUM
+        c.v[0] = mv.m0.changed ? v0 : -INFINITY;
+        c.v[1] = mv.m1.changed ? v1 : -INFINITY;
+        c.v[2] = mv.m2.changed ? v2 : -INFINITY;
+        c.v[3] = mv.m3.changed ? v3 : -INFINITY;
+    }
+    const bool ch[4] = {mv.m0.changed, mv.m1.changed, mv.m2.changed, mv.m3.changed};
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+        if (ch[d]) {
+            if (first_valid < 0) first_valid = d;
+            if (c.v[d] > c.value) {
+                c.value = c.v[d];
+                c.action = d;
+            }
+        }
+    if (c.action < 0 && first_valid >= 0) {     // every value was -inf or NaN (a poisoned table): still make a legal move
+        c.action = first_valid;
+        c.value = first_valid == 0 ? c.v[0] : first_valid == 1 ? c.v[1] : first_valid == 2 ? c.v[2] : c.v[3];
+    }
+    return c;
+}
+
+// choose with whichever LDS form the n-tuple size has
+template <int N>
+__device__ __forceinline__ Choice choose_lds(const float* __restrict__ w, const float* hot, const Moves4& mv) {
+    if constexpr (N <= 3)
+        return choose_small<N, false>(w, hot, mv);       // (k_td_play: one direction at a time for n = 3)
+    else
+        return choose_hot<N>(w, hot, mv);
+}
+
 template <int N>
 __global__ __launch_bounds__(WG) void k_eval_select(const uint4* boards, uint32_t B, const float* __restrict__ w, float* value,
                                                     uint8_t* action, float4* values4) {
@@ -614,6 +774,25 @@ __global__ __launch_bounds__(WG) void k_eval_select(const uint4* boards, uint32_
     action[i] = c.action < 0 ? (uint8_t)255 : (uint8_t)c.action;
     if (values4) values4[i] = make_float4(c.v[0], c.v[1], c.v[2], c.v[3]);
 }
+
+// k_eval_select with the table's LDS copy (n = 2, 3; BASELINE config 3 is the n = 3 case): a persistent grid, one workgroup
+// per CU, every thread takes boards i, i + threads, ...
+#define G2048_EVAL_LDS_KERNEL(NAME, NN, ATTR)                                                                                     \
+    __global__ __launch_bounds__(PLAY_HOT_WG) ATTR void NAME(const uint4* boards, uint32_t B, const float* __restrict__ w, float* value, uint8_t* action, \
+                                                             float4* values4) {                                                   \
+        extern __shared__ __attribute__((aligned(16))) float hot[];                                                               \
+        load_hot_set<NN, PLAY_HOT_WG>(hot, w);                                                                                    \
+        for (uint32_t i = blockIdx.x * PLAY_HOT_WG + threadIdx.x; i < B; i += gridDim.x * PLAY_HOT_WG) {                          \
+            Moves4 mv = all_moves(ld_board(boards, i));                                                                           \
+            Choice c = choose_small<NN, true>(w, hot, mv);                                                                           \
+            value[i] = c.action < 0 ? 0.0f : c.value;                                                                             \
+            action[i] = c.action < 0 ? (uint8_t)255 : (uint8_t)c.action;                                                          \
+            if (values4) values4[i] = make_float4(c.v[0], c.v[1], c.v[2], c.v[3]);                                                \
+        }                                                                                                                         \
+    }
+G2048_EVAL_LDS_KERNEL(k_eval_select_lds2, 2, )
+G2048_EVAL_LDS_KERNEL(k_eval_select_lds3, 3, __attribute__((amdgpu_waves_per_eu(PLAY_SMALL3_WAVES_PER_EU, PLAY_SMALL3_WAVES_PER_EU))))
+#undef G2048_EVAL_LDS_KERNEL
 
 // ------------------------------------------------------------------------------------------------ learning
 
@@ -808,9 +987,11 @@ __device__ __forceinline__ void td_play_body(LaneSet in, LaneSet out, const uint
     constexpr float F = (float)Shape<N>::F;
     const uint32_t* const perm = PERM ? perm_ : nullptr;       // (compile-time: a run-time test would put a wait behind every block's first load)
     __shared__ WgStats ws;
-    __shared__ __attribute__((aligned(16))) float hot[HOT ? HOT_SLOTS : 4];
+    // (DYNAMIC shared memory: with the 100+ KB known at compile time the compiler derives "one workgroup per CU" itself and
+    // drops the register budget that amdgpu_waves_per_eu asks for — see choose_hot)
+    extern __shared__ __attribute__((aligned(16))) float hot[];
     wg_stats_init(&ws);
-    if constexpr (HOT) load_hot_set<TPB>(hot, w);
+    if constexpr (HOT) load_hot_set<N, TPB>(hot, w);
     if (blockIdx.x == 0 && threadIdx.x < PLAY_SEGS) {
         recs.blocks_next[threadIdx.x * PLAY_SEG_STRIDE] = 0;
         if (threadIdx.x == 0) {
@@ -947,7 +1128,7 @@ __device__ __forceinline__ void td_play_body(LaneSet in, LaneSet out, const uint
             PHASE_STAMP(1);     // state loads + moves
             Choice c;
             if constexpr (HOT)
-                c = choose_hot<N>(w, hot, mv);
+                c = choose_lds<N>(w, hot, mv);
             else
                 c = choose<N>(w, mv);
             PHASE_STAMP(2);     // features, gathers, sums, select
@@ -1090,8 +1271,23 @@ __global__ __launch_bounds__(TPB, G2048_PLAY_MIN_WAVES) void k_td_play(LaneSet i
                                                                        GameLog lg, uint32_t static_rounds) {
     td_play_body<N, TPB, false, PERM>(in, out, perm, prev_nxt, B, w, alpha, recs, auto_reset, stats, lg, static_rounds);
 }
+// (n = 2: LDS reads only, no registers outside the allocator's range; n = 3: see choose_small)
 template <int N, int TPB, bool PERM>
-__global__ __launch_bounds__(TPB, G2048_PLAY_MIN_WAVES) __attribute__((amdgpu_num_vgpr(PLAY_HOT_COMPILER_VGPRS))) void k_td_play_hot(
+__global__ __launch_bounds__(TPB, G2048_PLAY_MIN_WAVES) void k_td_play_lds2(LaneSet in, LaneSet out, const uint32_t* __restrict__ perm, uint4* prev_nxt, uint32_t B,
+                                                                            const float* __restrict__ w, float alpha, TdRecs recs, int auto_reset, Stats* stats,
+                                                                            GameLog lg, uint32_t static_rounds) {
+    static_assert(N == 2, "n = 2");
+    td_play_body<N, TPB, true, PERM>(in, out, perm, prev_nxt, B, w, alpha, recs, auto_reset, stats, lg, static_rounds);
+}
+template <int N, int TPB, bool PERM>
+__global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(PLAY_SMALL3P_WAVES_PER_EU, PLAY_SMALL3P_WAVES_PER_EU))) void k_td_play_lds3(
+    LaneSet in, LaneSet out, const uint32_t* __restrict__ perm, uint4* prev_nxt, uint32_t B, const float* __restrict__ w, float alpha, TdRecs recs,
+    int auto_reset, Stats* stats, GameLog lg, uint32_t static_rounds) {
+    static_assert(N == 3, "n = 3");
+    td_play_body<N, TPB, true, PERM>(in, out, perm, prev_nxt, B, w, alpha, recs, auto_reset, stats, lg, static_rounds);
+}
+template <int N, int TPB, bool PERM>
+__global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(PLAY_HOT_WAVES_PER_EU, PLAY_HOT_WAVES_PER_EU))) void k_td_play_hot(
     LaneSet in, LaneSet out, const uint32_t* __restrict__ perm, uint4* prev_nxt, uint32_t B, const float* __restrict__ w, float alpha, TdRecs recs,
     int auto_reset, Stats* stats, GameLog lg, uint32_t static_rounds) {
     td_play_body<N, TPB, true, PERM>(in, out, perm, prev_nxt, B, w, alpha, recs, auto_reset, stats, lg, static_rounds);
@@ -2933,14 +3129,28 @@ int replan(g2048_ctx* c) {
     return build_slices(c);
 }
 
+// a kernel that takes more than 64 KB of dynamic LDS has to be told so once (per process: the attribute belongs to the function)
+template <class K>
+void allow_dynamic_lds(K kernel, uint32_t bytes) {
+    static bool done = false;
+    if (bytes > 65536u && !done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        done = true;
+    }
+}
+
 // workgroups of k_td_play: as many as are resident at once (occupancy x CUs), or fewer if the batch is small
 template <int N, int TPB, bool HOT>
 unsigned play_grid(g2048_ctx* c) {
     if (!c->play_wgs) {
         int per_cu = 0, cus = 0;
         hipError_t e;
-        if constexpr (HOT)
-            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_td_play_hot<N, TPB, false>, TPB, 0);
+        if constexpr (HOT && N == 2)
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_td_play_lds2<N, TPB, false>, TPB, HotShape<N>::SLOTS * 4u);
+        else if constexpr (HOT && N == 3)
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_td_play_lds3<N, TPB, false>, TPB, HotShape<N>::SLOTS * 4u);
+        else if constexpr (HOT)
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_td_play_hot<N, TPB, false>, TPB, HotShape<N>::SLOTS * 4u);
         else
             e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_td_play<N, TPB, false>, TPB, 0);
         if (e != hipSuccess || per_cu <= 0) per_cu = HOT ? 1 : 2;
@@ -2963,7 +3173,13 @@ uint32_t play_static_rounds(const g2048_ctx* c, unsigned grid, unsigned tpb) {
 // in two batches of two directions; +3 % for a fresh agent, -6 % for a trained one, and it compiled to 256 VGPRs + 12 bytes of
 // scratch — a spill between a hot gather's inline-asm load and its fence is exactly what that path must never have
 // (tools/check_codeobj.py enforces it at build time), so the variant is gone.)
-bool play_hot(const g2048_ctx* c) { return (c->n == 4 || c->n == 5) && c->knob.play_hot >= 1 && c->B >= c->knob.play_hot_min; }
+// n = 2, 3 (round 3): the whole table / its small-tile part in LDS (choose_small); their copies are smaller, so is the break-even
+bool play_hot(const g2048_ctx* c) {
+    if (c->knob.play_hot < 1) return false;
+    if (c->n == 2) return c->B >= c->knob.play_hot_min / 16u;
+    if (c->n == 3) return c->B >= c->knob.play_hot_min / 2u;
+    return (c->n == 4 || c->n == 5) && c->B >= c->knob.play_hot_min;
+}
 
 // One TD step on the context's stream: k_td_play, then the update in the selected mode.  `ev` (optional) gets an
 // event between the two parts.
@@ -3012,11 +3228,14 @@ int launch_td_step(g2048_ctx* c, float alpha, hipEvent_t ev = nullptr, hipEvent_
         }
     }
 #define G2048_PLAY_(KERNEL, NN, TPB, HOT, PERM)                                                                                      \
-    KERNEL<NN, TPB, PERM><<<play_grid<NN, TPB, HOT>(c), TPB, 0, c->stream>>>(lin, lout, perm, pn, B, c->w, alpha, recs, c->auto_reset, c->stats, c->log, \
-                                                                              play_static_rounds(c, play_grid<NN, TPB, HOT>(c), TPB))
+    (allow_dynamic_lds(KERNEL<NN, TPB, PERM>, HOT ? HotShape<NN>::SLOTS * 4u : 0u),                                                  \
+     KERNEL<NN, TPB, PERM><<<play_grid<NN, TPB, HOT>(c), TPB, HOT ? HotShape<NN>::SLOTS * 4u : 0u, c->stream>>>(                    \
+         lin, lout, perm, pn, B, c->w, alpha, recs, c->auto_reset, c->stats, c->log, play_static_rounds(c, play_grid<NN, TPB, HOT>(c), TPB)))
 #define G2048_PLAY(KERNEL, NN, TPB, HOT) (perm ? (G2048_PLAY_(KERNEL, NN, TPB, HOT, true)) : (G2048_PLAY_(KERNEL, NN, TPB, HOT, false)))
     if (play_hot(c)) {
         switch (c->n) {
+            case 2: G2048_PLAY(k_td_play_lds2, 2, PLAY_HOT_WG, true); break;
+            case 3: G2048_PLAY(k_td_play_lds3, 3, PLAY_HOT_WG, true); break;
             case 4: G2048_PLAY(k_td_play_hot, 4, PLAY_HOT_WG, true); break;
             default: G2048_PLAY(k_td_play_hot, 5, PLAY_HOT_WG, true); break;
         }
@@ -3572,7 +3791,14 @@ int g2048_eval_select(g2048_ctx* c, float* value, uint8_t* action, float* values
     float4* d_v4 = (float4*)c->scratch;
     float* d_v = (float*)((char*)c->scratch + B * 16);
     uint8_t* d_a = (uint8_t*)c->scratch + B * 20;
-    BY_N(c, (k_eval_select<N><<<grid_for(B), WG, 0, c->stream>>>(c->boards, c->B, c->w, d_v, d_a, values4 ? d_v4 : nullptr)));
+    // n = 2, 3 on batches big enough to pay for the copy: the LDS form, one workgroup per CU
+    const unsigned lds_grid = (unsigned)std::min<uint64_t>(256, (B + PLAY_HOT_WG - 1) / PLAY_HOT_WG);
+    if (c->n == 2 && c->knob.play_hot >= 1 && B >= (1u << 14))
+        k_eval_select_lds2<<<lds_grid, PLAY_HOT_WG, HotShape<2>::SLOTS * 4u, c->stream>>>(c->boards, c->B, c->w, d_v, d_a, values4 ? d_v4 : nullptr);
+    else if (c->n == 3 && c->knob.play_hot >= 1 && B >= (1u << 16))
+        allow_dynamic_lds(k_eval_select_lds3, HotShape<3>::SLOTS * 4u), k_eval_select_lds3<<<lds_grid, PLAY_HOT_WG, HotShape<3>::SLOTS * 4u, c->stream>>>(c->boards, c->B, c->w, d_v, d_a, values4 ? d_v4 : nullptr);
+    else
+        BY_N(c, (k_eval_select<N><<<grid_for(B), WG, 0, c->stream>>>(c->boards, c->B, c->w, d_v, d_a, values4 ? d_v4 : nullptr)));
     if (int rc = launched(c, "k_eval_select")) return rc;
     if (!value) return G2048_OK;            // device-only run (results stay in the context's scratch buffer; benchmarking)
     int rc;

@@ -7,7 +7,9 @@ spills nor copies nor reuses such a register between the load and the fence.  __
 the shipped lib2048_hip.so and FAILS the build if, in any k_td_play<*, *, HOT = true, *>:
 
   1. the kernel has scratch (private_segment_fixed_size > 0) or spilled VGPRs — a spill is how an in-flight value gets saved;
-  2. between a global_load_dword and the first s_waitcnt that guarantees its completion (vmcnt retires in order: the load is
+  2. any instruction other than the asm forms (ds_read_b32 into, global_load_dword into, v_add_f32 from) names a VGPR at or
+     above the register allocator's cap (amdgpu_waves_per_eu: v168 for the play kernels, v128 for k_eval_select_lds3);
+  3. between a global_load_dword and the first s_waitcnt that guarantees its completion (vmcnt retires in order: the load is
      done once vmcnt <= the number of vector-memory instructions issued after it), any instruction reads or writes the
      load's destination register.  The rule holds for compiler-scheduled loads as well (the compiler obeys it by
      construction), so every load of the kernel is checked, not only the asm ones.
@@ -142,9 +144,13 @@ def main():
     with tempfile.TemporaryDirectory() as tmp:
         co = extract_code_object(so, tmp)
         notes = kernel_notes(co)
-        hot = [k for k in notes if re.search(r'k_td_play_hotILi\d+ELi\d+ELb[01]E', k)]
-        if not hot:
-            failures.append('no k_td_play_hot<*, *, *> kernel found in the code object (did the mangling change?)')
+        # the kernels whose gathers land in registers outside the allocator's range (choose_hot, choose_small<3>)
+        guarded = {'k_td_play_hot': 4 * 17, 'k_td_play_lds3': 2 * 52, 'k_eval_select_lds3': 2 * 52}
+        cap = {'k_td_play_hot': 168, 'k_td_play_lds3': 168, 'k_eval_select_lds3': 128}      # first VGPR outside the allocator's range (amdgpu_waves_per_eu)
+        hot = [k for k in notes if any(g in k for g in guarded)]
+        for g in guarded:
+            if not any(g in k for k in hot):
+                failures.append(f'no {g} kernel found in the code object (did the mangling change?)')
         for k in sorted(notes):
             d = notes[k]
             if d['private_segment_fixed_size'] > 0 or d['vgpr_spill_count'] > 0:
@@ -152,25 +158,41 @@ def main():
                 print(f'[codeobj] note: {short}: scratch {d["private_segment_fixed_size"]} B, {d["vgpr_count"]} VGPRs, {d["vgpr_spill_count"]} spilled')
         for k in hot:
             d = notes[k]
-            tag = re.search(r'k_td_play_hotILi(\d+)ELi(\d+)ELb([01])E', k)
-            name = f'k_td_play_hot<{tag.group(1)}, {tag.group(2)}, {"true" if tag.group(3) == "1" else "false"}>'
+            kind = next(g for g in guarded if g in k)
+            tag = re.search(kind + r'I?((?:L[ib]\d+E)*)', k)
+            params = ', '.join(re.findall(r'L[ib](\d+)E', tag.group(1))) if tag else ''
+            name = f'{kind}<{params}>' if params else kind
             if d['private_segment_fixed_size'] != 0 or d['vgpr_spill_count'] != 0:
-                failures.append(f'{name}: scratch {d["private_segment_fixed_size"]} B, {d["vgpr_spill_count"]} spilled VGPRs — the in-flight '
-                                f'registers of the hot gathers may have been spilled')
+                failures.append(f'{name}: scratch {d["private_segment_fixed_size"]} B, {d["vgpr_spill_count"]} spilled VGPRs — the register '
+                                f'allocator ran out below the cap, and a spilled value is how an in-flight register gets saved')
             ins = disassemble(co, k)
             loads = sum(1 for _, x, _ in ins if x.startswith('global_load_dword '))
             fences = sum(1 for _, x, _ in ins if x.startswith('s_waitcnt vmcnt(0)'))
             bad = check_inflight(ins)
             print(f'[codeobj] {name}: {d["vgpr_count"]} VGPRs, scratch {d["private_segment_fixed_size"]} B, LDS {d["group_segment_fixed_size"]} B, '
                   f'{len(ins)} instructions, {loads} global_load_dword, {fences} full vmcnt fences, {len(bad)} in-flight register touches')
-            if loads < 4 * 17:
-                failures.append(f'{name}: only {loads} global_load_dword (expected >= 68 per loop copy): is the hot path still there?')
+            # the registers above the cap belong to the asm statements: LDS read into, masked global load into, v_add_f32 from
+            foreign = []
+            for _, text, _ in ins:
+                op, _, rest = text.partition(' ')
+                high = [r for r in vregs(rest) if r >= cap[kind]]
+                if not high:
+                    continue
+                ops = [o.strip() for o in rest.split(',')]
+                ok = (op in ('ds_read_b32', 'global_load_dword') and vregs(ops[0]) == set(high) and not any(r >= cap[kind] for r in vregs(','.join(ops[1:])))) or \
+                     (op in ('v_add_f32', 'v_add_f32_e32') and len(ops) == 3 and vregs(ops[2]) == set(high) and not any(r >= cap[kind] for r in vregs(ops[0] + ',' + ops[1])))
+                if not ok:
+                    foreign.append(text)
+            if foreign:
+                failures.append(f'{name}: {len(foreign)} instruction(s) outside the asm forms name a VGPR >= v{cap[kind]}, e.g. "{foreign[0]}" — the register allocator was not held below the cap')
+            if loads < guarded[kind]:
+                failures.append(f'{name}: only {loads} global_load_dword (expected >= {guarded[kind]}): is the LDS + masked-load path still there?')
             for li, oi in bad[:5]:
                 failures.append(f'{name}: "{ins[oi][1]}" names the destination of "{ins[li][1]}" (issued {oi - li} instructions earlier) on a path without a covering s_waitcnt')
     if failures:
         print('\n'.join('[codeobj] FAIL: ' + f for f in failures))
         return 1
-    print('[codeobj] ok: no scratch in the hot-set kernels, no instruction touches a load destination before its wait')
+    print('[codeobj] ok: no scratch in the guarded kernels, no instruction names the destination of a load before a wait that covers it')
     return 0
 
 
