@@ -1,9 +1,11 @@
-"""ctypes binding of include/g2048.h (lib2048_hip.so).
+"""ctypes binding of include/g2048.h.
 
-There is no CPU implementation: if the shared library has not been built, importing the symbols
-fails loudly; if it is built but no GPU is visible, `g2048_create` returns G2048_ERR_NODEV and
-`check` raises.  Build with `python -c "import __graft_entry__ as g; g.build()"` or
-`make -C 2048_amd/csrc`.
+Two libraries implement the ABI: lib2048_hip.so (the product: hand-written HIP for gfx950) and lib2048_cpu.so (csrc/cpu_ref.cpp:
+the same entry points in scalar C++ from the same integer headers, for boxes without a GPU and as a CPU baseline).  Which one
+a process uses is an EXPLICIT choice — `Engine(backend='cpu')` or G2048_BACKEND=cpu in the environment; the default is 'hip'
+and there is no fallback from one to the other: if lib2048_hip.so has not been built, loading fails loudly; if it is built
+but no GPU is visible, `g2048_create` returns G2048_ERR_NODEV and `check` raises.  Build with
+`python -c "import __graft_entry__ as g; g.build()"` or `make -C 2048_amd/csrc`.
 """
 import ctypes
 import os
@@ -11,6 +13,16 @@ from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_uint8,
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('G2048_LIB') or os.path.join(HERE, 'lib2048_hip.so')        # (G2048_LIB: experiment builds)
+CPU_LIB_PATH = os.path.join(HERE, 'lib2048_cpu.so')
+BACKENDS = ('hip', 'cpu')
+
+
+def default_backend():
+    """'hip' unless G2048_BACKEND says otherwise (read at every call: a test may set it for one engine)."""
+    b = os.environ.get('G2048_BACKEND', 'hip')
+    if b not in BACKENDS:
+        raise ValueError(f'G2048_BACKEND={b!r}: expected one of {BACKENDS}')
+    return b
 
 OK, ERR_ARG, ERR_HIP, ERR_NOMEM, ERR_STATE, ERR_NODEV, ERR_COMM = 0, -1, -2, -3, -4, -5, -6
 COMM_ID_BYTES = 128
@@ -101,30 +113,32 @@ SIGNATURES = {
     'g2048_allreduce_f64': (c_int, [_P, _P, c_int, c_int]),
 }
 
-_lib = None
+_libs = {}
 
 
-def load():
-    """Load lib2048_hip.so (once).  Raises if it is missing — there is no fallback."""
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise G2048Error(ERR_NODEV, f'{LIB_PATH} is not built; run __graft_entry__.build() '
-                                        f'(hipcc --offload-arch=gfx950).  There is no CPU fallback.')
-        lib = ctypes.CDLL(LIB_PATH)
+def load(backend=None):
+    """Load the library of `backend` ('hip' | 'cpu' | None = default_backend()), once.  Raises if it is missing — there is no
+    fallback between the two."""
+    backend = backend or default_backend()
+    if backend not in _libs:
+        path = LIB_PATH if backend == 'hip' else CPU_LIB_PATH
+        if not os.path.exists(path):
+            raise G2048Error(ERR_NODEV, f'{path} is not built; run __graft_entry__.build() '
+                                        + ('(hipcc --offload-arch=gfx950).  There is no CPU fallback.' if backend == 'hip' else '(g++ -fopenmp csrc/cpu_ref.cpp).'))
+        lib = ctypes.CDLL(path)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)          # AttributeError here = header and library disagree
             fn.restype = res
             fn.argtypes = args
         if lib.g2048_abi_version() != 2:
             raise G2048Error(ERR_STATE, 'ABI version mismatch')
-        _lib = lib
-    return _lib
+        _libs[backend] = lib
+    return _libs[backend]
 
 
-def check(status, ctx=None):
+def check(status, ctx=None, lib=None):
     if status != OK:
-        lib = load()
+        lib = lib or load()
         msg = lib.g2048_strerror(status).decode()
         if ctx:
             detail = lib.g2048_last_error(ctx).decode()

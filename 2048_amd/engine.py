@@ -18,7 +18,7 @@ def _buf(a):
 
 
 def table_slots(n):
-    return int(_lib.load().g2048_table_slots(n))
+    return int(_lib.load().g2048_table_slots(n))      # (geometry: the same in both libraries)
 
 
 def feature_layout(n):
@@ -30,20 +30,25 @@ def feature_layout(n):
 
 
 class Engine:
-    def __init__(self, batch, n=0, seed=2048, lane0=0, device=0, share_table_of=None):
-        """share_table_of: another Engine whose weight table this one uses (g2048_create_shared)."""
-        self.lib = _lib.load()
+    def __init__(self, batch, n=0, seed=2048, lane0=0, device=0, share_table_of=None, backend=None):
+        """share_table_of: another Engine whose weight table this one uses (g2048_create_shared).
+        backend: 'hip' (lib2048_hip.so, the default) or 'cpu' (lib2048_cpu.so, csrc/cpu_ref.cpp) — None takes G2048_BACKEND
+        from the environment; an explicit choice either way, never a fallback."""
         if share_table_of is not None:
-            n, device = share_table_of.n, share_table_of.device
+            n, device, backend = share_table_of.n, share_table_of.device, share_table_of.backend
+        self.backend = backend or _lib.default_backend()
+        self.lib = _lib.load(self.backend)
+        if share_table_of is not None:
+            pass
         self.batch, self.n, self.seed, self.lane0, self.device = int(batch), int(n), int(seed), int(lane0), int(device)
         self.num_feat = NUM_FEAT.get(self.n, 0)
         self.slots = table_slots(self.n) if self.n else 0
         self.parent = share_table_of                      # keeps the table's owner alive
         ctx = ctypes.c_void_p()
         if share_table_of is None:
-            check(self.lib.g2048_create(self.device, self.batch, self.n, self.seed & (2 ** 64 - 1), self.lane0, ctypes.byref(ctx)))
+            check(self.lib.g2048_create(self.device, self.batch, self.n, self.seed & (2 ** 64 - 1), self.lane0, ctypes.byref(ctx)), None, self.lib)
         else:
-            check(self.lib.g2048_create_shared(share_table_of.ctx, self.batch, self.seed & (2 ** 64 - 1), self.lane0, ctypes.byref(ctx)))
+            check(self.lib.g2048_create_shared(share_table_of.ctx, self.batch, self.seed & (2 ** 64 - 1), self.lane0, ctypes.byref(ctx)), None, self.lib)
         self.ctx = ctx
 
     def close(self):
@@ -54,7 +59,7 @@ class Engine:
     __del__ = close
 
     def _c(self, status):
-        check(status, self.ctx)
+        check(status, self.ctx, self.lib)
 
     # ---- lane state
     def set_boards(self, boards, clear_carry=True):
