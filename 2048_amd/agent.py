@@ -18,6 +18,7 @@ Batch 1 always uses 'sum' with the reference's alpha and reproduces the referenc
 from .game import *  # noqa: F401,F403  (r_learning.py:3 star-imports game_logic the same way)
 from .game import Game, np, pickle, time, deque, load_s3, save_s3, Logger, AGENT_PANE, RUNNING, dash_intervals
 
+from . import _lib
 from .engine import Engine, NUM_FEAT, feature_layout
 
 
@@ -37,9 +38,10 @@ _FEATURE_ENGINES = {}
 
 
 def _features(n, x):
-    eng = _FEATURE_ENGINES.get(n)
+    key = (_lib.default_backend(), n)
+    eng = _FEATURE_ENGINES.get(key)
     if eng is None:
-        eng = _FEATURE_ENGINES[n] = _TableFree(n)
+        eng = _FEATURE_ENGINES[key] = _TableFree(n)
     return eng(x)
 
 

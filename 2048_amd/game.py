@@ -34,8 +34,9 @@ class _Device:
         self.moves = None
 
     def engine(self):
-        if self.eng is None:
-            self.eng = Engine(1, n=0, seed=2048)
+        backend = _lib.default_backend()                      # (the backend is an explicit, per-process choice: G2048_BACKEND)
+        if self.eng is None or self.eng.backend != backend:
+            self.eng, self.key = Engine(1, n=0, seed=2048, backend=backend), None
         return self.eng
 
     def move_all(self, row):
