@@ -34,15 +34,34 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+L2_PEAK_GBS = 34500.0                      # MI355X_MICROARCH.md, L2 (per XCD, aggregate): ~34.5 TB/s
+LDS_ATOMIC_PEAK = 4.1 * 256 * 2.4e9        # ds_add_u64 lane-adds/s, chip-wide: 4.1 per cycle per CU (profiles/r01_lds_atomic_microbench.txt) x 256 CUs x 2.4 GHz
 NUM_FEAT = {2: 24, 3: 52, 4: 17, 5: 21, 6: 33}
+ORBIT_ADDS = {2: 24, 3: 52, 4: 17, 5: 21, 6: 21}          # LDS adds per record after the orbit / coset reduction (n = 6: + 16 binned pairs)
 
 
 def algorithmic_bytes(n):
-    """Per board-step, SURVEY.md §8(d): env 72 + gathers 4*F*4 + scatter 8*F*(4R+4W) + carry 2*20.
-    Split by kernel: k_td_play = env + gathers + carry write; the update kernels = scatter + carry read."""
+    """Per board-step, SURVEY.md 8(d): env 72 + gathers 4*F*4 + scatter 8*F*(4R+4W) + carry 2*20 — the REFERENCE algorithm's
+    bytes.  Split: k_td_play = env + gathers + carry write.  The scatter term (8 F read-modify-writes of the table) is what the
+    reference does, not what this implementation moves (see implementation_bytes); it is quoted for the record only."""
     F = NUM_FEAT[n]
     play = 72 + 4 * F * 4 + 20
     update = 8 * F * 8 + 20
+    return play, update
+
+
+def implementation_bytes(n):
+    """Bytes per lane and step that THIS implementation must move through HBM when nothing but the table is cache-resident
+     — the denominator of the whole-step fraction:
+      k_td_play   reads  board 16 + rng 16 + score 4 + label 4 + flags 1 + lane id 4                    = 45
+                  writes board 16 + rng 16 + score 4 + label 4 + flags 1 + last move 2 + afterstate 16
+                         + dw 4 + orbit-index record 50 (n >= 4)                                        = 63 (+ 50)
+      update      reads  the record once: orbit indices 50 + dw 4 (n >= 4) or afterstate 16 + dw 4      = 54 | 20
+      apply       the orbit tables once (read, clear the other buffer): a per-launch constant, quoted apart
+    The table gathers and the LDS adds are NOT here: the table is L2 / Infinity-Cache resident by design."""
+    rec = 50 if n >= 4 else 0
+    play = 45 + 63 + rec
+    update = (50 + 4) if n >= 4 else (16 + 4)
     return play, update
 
 
@@ -66,9 +85,39 @@ def cpu_baseline(n, seconds):
         moves += m
         games += 1
     dt = time.perf_counter() - t0
-    return dict(value=moves / dt, unit='board-steps/s', cores=1, kind='port',
-                sample=f'{games} whole TD(0) episodes, n={n}, batch 1, {moves} board-steps in {dt:.1f} s '
-                       f'(oracle/ref_scalar.py, NumPy {np.__version__}, host has {os.cpu_count()} logical cores)')
+    out = dict(value=moves / dt, unit='board-steps/s', cores=1, kind='port',
+               sample=f'{games} whole TD(0) episodes, n={n}, batch 1, {moves} board-steps in {dt:.1f} s '
+                      f'(oracle/ref_scalar.py, NumPy {np.__version__}, host has {os.cpu_count()} logical cores); '
+                      f'calibration against the imported reference on one core: BASELINE.md section 4 (port / reference = 0.90 - 1.19)')
+    try:
+        out['cpu_ref'] = cpu_ref_lines(pkg, n)
+    except Exception as e:              # the second CPU line must not take the benchmark line down
+        out['cpu_ref'] = {'error': repr(e)}
+    return out
+
+
+def cpu_ref_lines(pkg, n, seconds=4.0, batch=4096):
+    """The stronger CPU line: the build's own C++ backend behind the same C ABI
+    (lib2048_cpu.so, 2048_amd/csrc/cpu_ref.cpp — the kernels' integer headers compiled for the host; explicit backend, not a
+    fallback and not the oracle), the same synchronous TD(0) step on `batch` lanes, 1 thread and all host threads."""
+    lines = {'what': f'lib2048_cpu.so (csrc/cpu_ref.cpp), full TD(0) step, n={n}, {batch} lanes, sum rule, ~{seconds:.0f} s each', 'unit': 'board-steps/s'}
+    allt = max(1, min(os.cpu_count() or 1, 64))
+    for label, threads, lanes in (('one_thread', 1, batch), ('all_threads', allt, batch * 16)):
+        os.environ['G2048_CPU_THREADS'] = str(threads)
+        eng = pkg.Engine(lanes, n=n, seed=2048, backend='cpu')
+        eng.init_weights(seed=7, scale=0.01)
+        alpha = 0.25 * NUM_FEAT[n] / (8.0 * lanes)
+        eng.td_steps(alpha, 8)
+        steps, chunk = 0, 8
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            eng.td_steps(alpha, chunk)
+            steps += chunk
+        dt = time.perf_counter() - t0
+        eng.close()
+        lines[label] = {'value': steps * lanes / dt, 'threads': threads, 'lanes': lanes}
+    os.environ.pop('G2048_CPU_THREADS', None)
+    return lines
 
 
 def measured_copy_gbps(device):
@@ -125,6 +174,134 @@ def side_workload(pkg, args):
                    algorithmic_GBps=by * B * args.steps / (ms * 1e-3) / 1e9)
     emit(out)
     eng.close()
+
+
+def lib_sha256():
+    import hashlib
+    with open(os.path.join(ROOT, '2048_amd', 'lib2048_hip.so'), 'rb') as f:
+        return hashlib.sha256(f.read()).hexdigest()
+
+
+def load_traffic(n, B):
+    """PMC-measured per-launch counters of the kernels (tools/pmc_traffic.py -> profiles/traffic.json), valid only for the
+    library they were measured on: the file carries the sha256 of lib2048_hip.so and a stale stamp yields nothing."""
+    path = os.path.join(ROOT, 'profiles', 'traffic.json')
+    if not os.path.exists(path):
+        return None, 'profiles/traffic.json absent'
+    with open(path) as f:
+        t = json.load(f)
+    if t.get('so_sha256') != lib_sha256():
+        return None, 'profiles/traffic.json was measured on another build of lib2048_hip.so (stale stamp): rerun tools/r03_profiles.sh'
+    entry = t.get('entries', {}).get(f'n{n}_b{B}')
+    return entry, (None if entry else f'no PMC entry for n={n}, {B} lanes')
+
+
+def build_roofline(eng, n, B, ms_step, ms_play, ms_owner, ms_tail, ms_apply, st, copy_gbps):
+    """The measurement block (prompt section 4).  Top level: the contract's fields for the dominant
+    kernel — `achieved` = the reference algorithm's bytes for that kernel over its measured duration, against the
+    8 TB/s HBM peak, `traffic` = its PMC-measured HBM bytes.  Below it, per kernel, the bound each one actually hits, every
+    fraction <= 1 by construction (bytes or operations the kernel really moves / performs over its own time):
+      k_td_play          L2 -> L1 request bytes (TCP_TCC_READ_REQ x 64 B, PMC) against the L2 peak; VALU-busy share (PMC)
+      k_td_update_owner  record bytes its workgroups scan (from the plan in force) against the L2 peak; LDS atomic adds against
+                         the measured ds_add_u64 rate
+      whole step         PMC-measured HBM bytes against 8 TB/s, and the implementation's compulsory bytes (implementation_bytes)"""
+    by_play, by_update = algorithmic_bytes(n)
+    im_play, im_update = implementation_bytes(n)
+    play_name = f'k_td_play<{n}>'
+    kernels_ms = {play_name: ms_play, f'k_td_update_owner<{n}>': ms_owner, 'k_apply_orbits': ms_apply}
+    if n == 6:
+        kernels_ms['k_hex_* (f_6 orbits: count, plan, scatter, owner)'] = ms_tail
+    dominant = max(kernels_ms, key=kernels_ms.get)
+    pmc, pmc_note = load_traffic(n, B)
+    pmc = pmc or {}
+
+    def pm(kernel, counter):
+        v = pmc.get(kernel, {}).get(counter)
+        return float(v) if v is not None else None
+
+    achieved = by_play * B / (ms_play * 1e-3) / 1e9
+    out = {'bound': 'hbm', 'kernel': play_name, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+           'traffic': pm('k_td_play', 'hbm_bytes'), 'traffic_source': pmc_note or 'profiles/traffic.json (tools/pmc_traffic.py), same lib2048_hip.so',
+           'algorithmic_bytes_per_launch': by_play * B, 'ms_per_launch': ms_play, 'longest_kernel': dominant, 'ms_kernels': kernels_ms,
+           'note': 'achieved = reference-algorithm bytes (SURVEY.md 8d: 72 + 4 F 4 + 20 per board-step) / kernel time: the contract\'s yardstick.  '
+                   'The table gathers it counts are served by L2 / LDS, not HBM: the bounds the kernels really hit are under `kernels`.'}
+    kern = {}
+    # ---- k_td_play
+    k = {'ms': ms_play, 'share_of_step': ms_play / ms_step, 'limits': []}
+    req = pm('k_td_play', 'TCP_TCC_READ_REQ_sum')
+    if req is not None:
+        l2 = req * 64.0 / (ms_play * 1e-3) / 1e9
+        k['limits'].append({'bound': 'l2', 'what': 'L2 -> L1 read requests x 64 B (PMC TCP_TCC_READ_REQ_sum)', 'bytes_per_launch': req * 64.0,
+                            'achieved': l2, 'peak': L2_PEAK_GBS, 'unit': 'GB/s', 'frac': l2 / L2_PEAK_GBS})
+    valu, cyc = pm('k_td_play', 'SQ_ACTIVE_INST_VALU'), pm('k_td_play', 'GRBM_GUI_ACTIVE')
+    if valu is not None and cyc:
+        # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the chip's 1 024 SIMDs (MI355X_MICROARCH.md, PMC units)
+        busy = valu * 4.0 / 1024.0 / cyc
+        k['limits'].append({'bound': 'valu', 'what': 'SQ_ACTIVE_INST_VALU x 4 / 1024 SIMDs / GRBM_GUI_ACTIVE', 'busy_frac': busy})
+    hb = pm('k_td_play', 'hbm_bytes')
+    if hb is not None:
+        g = hb / (ms_play * 1e-3) / 1e9
+        k['limits'].append({'bound': 'hbm', 'what': 'PMC FETCH_SIZE + WRITE_SIZE (corrected, tools/pmc_traffic.py)', 'bytes_per_launch': hb, 'achieved': g,
+                            'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': g / HBM_PEAK_GBS})
+    k['compulsory_hbm_bytes_per_launch'] = im_play * B
+    kern[play_name] = k
+    # ---- k_td_update_owner: what its plan makes it scan
+    k = {'ms': ms_owner, 'share_of_step': ms_owner / ms_step, 'limits': []}
+    try:
+        plan = eng.debug_owner_plan()
+        rec_bytes = {0: 12, 1: 12, 2: 12, 3: 12, 4: 6, 5: 20} if n >= 4 else {}
+        scans = {}
+        for row in plan:
+            scans[(int(row[0]), int(row[1]))] = 1
+        scanned = sum((rec_bytes.get(v, 20) if n >= 4 else 20) * B for (v, _) in scans)
+        if scanned and ms_owner > 0:
+            g = scanned / (ms_owner * 1e-3) / 1e9
+            k['limits'].append({'bound': 'l2', 'what': f'{len(scans)} chunk scans of the step\'s records (8 + 4, 16 + 4 or 2 + 4 bytes per record and scan), L2 / Infinity-Cache resident',
+                                'bytes_per_launch': scanned, 'achieved': g, 'peak': L2_PEAK_GBS, 'unit': 'GB/s', 'frac': g / L2_PEAK_GBS})
+    except Exception as e:
+        k['plan_error'] = repr(e)
+    if ms_owner > 0:
+        adds = ORBIT_ADDS[n] * B * 1.0
+        rate = adds / (ms_owner * 1e-3)
+        k['limits'].append({'bound': 'lds-atomic', 'what': f'{ORBIT_ADDS[n]} ds_add_u64 per record (orbit + coset reduced; every lane has a record in steady state)',
+                            'adds_per_launch': adds, 'achieved': rate, 'peak': LDS_ATOMIC_PEAK, 'unit': 'adds/s', 'frac': rate / LDS_ATOMIC_PEAK})
+    hb = pm('k_td_update_owner', 'hbm_bytes')
+    if hb is not None:
+        g = hb / (ms_owner * 1e-3) / 1e9
+        k['limits'].append({'bound': 'hbm', 'what': 'PMC FETCH_SIZE + WRITE_SIZE', 'bytes_per_launch': hb, 'achieved': g, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                            'frac': g / HBM_PEAK_GBS})
+    k['compulsory_hbm_bytes_per_launch'] = im_update * B
+    kern[f'k_td_update_owner<{n}>'] = k
+    # ---- k_apply_orbits: two streams over the orbit tables (read this step's, clear the next one's) + the touched table entries
+    k = {'ms': ms_apply, 'share_of_step': ms_apply / ms_step, 'limits': []}
+    hb = pm('k_apply_orbits', 'hbm_bytes')
+    if hb is not None and ms_apply > 0:
+        g = hb / (ms_apply * 1e-3) / 1e9
+        k['limits'].append({'bound': 'hbm', 'what': 'PMC FETCH_SIZE + WRITE_SIZE', 'bytes_per_launch': hb, 'achieved': g, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                            'frac': g / HBM_PEAK_GBS})
+    kern['k_apply_orbits'] = k
+    out['kernels'] = kern
+    # ---- whole step
+    step_hbm = None
+    if pmc:
+        vals = [v.get('hbm_bytes') for v in pmc.values() if isinstance(v, dict) and v.get('hbm_bytes') is not None]
+        step_hbm = float(sum(vals)) if vals else None
+    comp = (im_play + im_update) * B
+    ws = {'ms': ms_step, 'compulsory_hbm_bytes': comp, 'compulsory_GBps': comp / (ms_step * 1e-3) / 1e9,
+          'compulsory_frac_of_hbm_peak': comp / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+          'reference_algorithm_bytes': (by_play + by_update) * B,
+          'note': 'compulsory = what this implementation must stream per step when only the table is cache-resident (implementation_bytes: '
+                  f'{im_play} + {im_update} B per lane); reference_algorithm_bytes (SURVEY.md 8d, {by_play + by_update} B per board-step) is the reference\'s '
+                  'gather + 8-image read-modify-write count, most of which this implementation turns into LDS adds: quoted for the record, not as a rate'}
+    if step_hbm is not None:
+        ws.update({'hbm_bytes_measured': step_hbm, 'hbm_GBps': step_hbm / (ms_step * 1e-3) / 1e9,
+                   'frac_of_hbm_peak': step_hbm / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS})
+    out['whole_step'] = ws
+    out['measured_copy_GBps'] = copy_gbps
+    fr = [out['frac'], ws['compulsory_frac_of_hbm_peak']] + [lim['frac'] for kk in kern.values() for lim in kk['limits'] if 'frac' in lim]
+    if any(f > 1.0 for f in fr):
+        out['invalid'] = 'a fraction above 1: bookkeeping error'
+    return out
 
 
 _RESULT_FD = None
@@ -270,6 +447,8 @@ def main():
     ap.add_argument('--epoch', type=int, default=50, help='steps between weight-delta all-reduces (N > 1)')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--trained-steps', type=int, default=3000,
+                    help='after the mean-rule leg: train this many more steps under the mean rule, then time K steps on the trained agent\'s boards (0: skip)')
     ap.add_argument('--no-mean-line', action='store_true', help='skip the secondary measurement of the per-slot mean rule')
     ap.add_argument('--workload', default='td', choices=['td', 'env', 'eval'],
                     help='td = BASELINE config 4 (the metric); env = config 2 (65 536 lanes, env step only); eval = config 3 '
@@ -382,44 +561,8 @@ def main():
 
     # per-kernel launch durations (HIP events on the context's stream), after the timed regions
     ms_play, ms_owner, ms_tail, ms_apply = eng.td_steps_kernel_ms(alpha, 20)
-    by_play, by_update = algorithmic_bytes(n)
-    kernels = {f'k_td_play<{n}>': ms_play, f'k_td_update_owner<{n}>': ms_owner, 'k_apply_orbits': ms_apply}
-    if n == 6:
-        kernels['k_td_update_tail<6>'] = ms_tail
-    dominant = max(kernels, key=kernels.get)
-    traffic_all = {}
-    tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
-    if os.path.exists(tpath):
-        with open(tpath) as f:
-            traffic_all = json.load(f)
-    # `achieved`: algorithmic bytes of k_td_play's launch (72 + 4 F 4 + 20 per board-step) over its measured
-    # duration.  The update kernels remove most of their algorithmic bytes (orbit and coset reductions, LDS accumulation):
-    # a fraction is never computed from bytes a kernel does not move.
     ms_step = dt / K * 1e3
-    # (k_td_play is quoted even if an update kernel should ever be the longest: it is the only kernel whose algorithmic
-    # bytes are bytes it moves; `longest_kernel` says which one took the most time)
-    r_kernel, r_bytes, r_ms = f'k_td_play<{n}>', by_play * B, ms_play
-    traffic_step = sum(v for k, v in traffic_all.items() if k.endswith(f'_b{B}') and isinstance(v, (int, float))) or None
-    achieved = r_bytes / (r_ms * 1e-3) / 1e9
-    roofline = {'bound': 'hbm', 'kernel': r_kernel, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic_all.get(f'{r_kernel}_b{B}'), 'longest_kernel': dominant,
-                'algorithmic_bytes_per_launch': r_bytes, 'ms_per_launch': r_ms,
-                'ms_kernels': kernels,
-                'k_td_play': {'algorithmic_bytes_per_launch': by_play * B, 'ms': ms_play,
-                              'GBps': by_play * B / (ms_play * 1e-3) / 1e9, 'frac': by_play * B / (ms_play * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                              # its own bound is not HBM: 4 x num_feat divergent 4-byte gathers per lane, one cache line per
-                              # cycle through each CU's address path
-                              'limited_by': 'L1 misses of the cold table gathers served by L2 (the table is cache-resident; the hot entries come from LDS), VALU issue and per-block latency; DESIGN.md section 4'},
-                # the survey's per-step figure (1 792 B at n = 5) over the step time.  NOT a fraction of a bound: most of those
-                # bytes never reach HBM — the table and the records are cache-resident, the orbit and coset reductions drop 27
-                # of the reference's 48 adds per feature group, a third of the gathers come from LDS — so it can exceed the peak.
-                'whole_step': {'algorithmic_bytes': (by_play + by_update) * B, 'ms': ms_step,
-                               'GBps': (by_play + by_update) * B / (ms_step * 1e-3) / 1e9,
-                               'ratio_to_hbm_peak': (by_play + by_update) * B / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                               'hbm_bytes_measured': traffic_step},
-                'measured_copy_GBps': copy_gbps}
-    if roofline['frac'] > 1.0 or roofline['k_td_play']['frac'] > 1.0:      # cannot happen for bytes a kernel really moves
-        roofline['invalid'] = 'fraction above 1: bookkeeping error'
+    roofline = build_roofline(eng, n, B, ms_step, ms_play, ms_owner, ms_tail, ms_apply, st, copy_gbps)
 
     comm = None
     if sync:
@@ -457,6 +600,27 @@ def main():
         mean_line = {'update_rule': 'mean', 'value': B * K / (mm * 1e-3), 'unit': 'board-steps/s', 'ms_per_step': mm / K,
                      'alpha': args.alpha}
 
+    trained = None
+    if mean_line is not None and args.trained_steps > 0:
+        # the number a user of QAgent.train_run sees: the per-slot mean rule on the boards of an agent that has learned for
+        # `--trained-steps` steps in this very run (bigger tiles: colder gathers, more busy chunks); same lanes, same kernels
+        eng.stats_reset()
+        t0 = time.perf_counter()
+        eng.td_steps(args.alpha, args.trained_steps)
+        eng.sync()
+        train_s = time.perf_counter() - t0
+        tt = []
+        for _ in range(max(1, args.repeats)):
+            eng.timer_start()
+            eng.td_steps(args.alpha, K)
+            tt.append(eng.timer_stop())
+        tm = statistics.median(tt)
+        ts = eng.stats()
+        kp, ko, kt, ka = eng.td_steps_kernel_ms(args.alpha, 20)
+        trained = {'update_rule': 'mean', 'trained_steps': args.trained_steps, 'trained_seconds': train_s, 'episodes_while_training': ts['episodes'],
+                   'mean_score_while_training': ts['score_sum'] / max(1, ts['episodes']), 'value': B * K / (tm * 1e-3), 'unit': 'board-steps/s',
+                   'ms_per_step': tm / K, 'ms_kernels': {'k_td_play': kp, 'k_td_update_owner': ko, 'k_apply_orbits_mean': ka}}
+
     if rank == 0:
         out = {
             'metric': 'board-steps/sec at batch 2^20 (full TD(0) step: move x4, n-tuple gather, greedy select, 8-symmetry scatter-add, spawn)',
@@ -480,6 +644,8 @@ def main():
         }
         if mean_line:
             out['mean_rule'] = mean_line
+        if trained:
+            out['trained_agent'] = trained
         if comm:
             out['comm'] = comm
         if world == 1 and not args.no_cpu_baseline:
