@@ -238,7 +238,7 @@ class QAgent:
     # ---- persistence (r_learning.py:166-200): parameters and weights are stored separately in 's3' mode
 
     def __getstate__(self):
-        state = {k: v for k, v in self.__dict__.items() if k not in ('_engine', '_solo', '_pending_weights', 'print', '_dist', '_sync')}
+        state = {k: v for k, v in self.__dict__.items() if k not in ('_engine', '_solo', '_pending_weights', 'print', '_dist', '_sync', '_shared_best')}
         state['weights'] = self.list_to_np() if (self._engine is not None or self._pending_weights is not None) else None
         return state
 
@@ -263,7 +263,7 @@ class QAgent:
             nps = self.list_to_np()
             params = QAgent(name=self.name, with_weights=False)
             for key, value in self.__dict__.items():
-                if key not in ('_engine', '_solo', '_pending_weights', '_dist', '_sync'):
+                if key not in ('_engine', '_solo', '_pending_weights', '_dist', '_sync', '_shared_best'):
                     setattr(params, key, value)
             save_s3(params, 'a/' + self.file)
             save_s3(nps, 'weights/' + self.file)
@@ -483,6 +483,7 @@ class QAgent:
         eng.set_auto_reset(True)
         sync = self._epoch_sync()
         chief = self.rank == 0
+        own_print = self.print
         if not chief:
             saving = False                                    # rank 0 prints, keeps the best game and saves
             self.print = lambda *a, **k: None
@@ -521,18 +522,27 @@ class QAgent:
             while self.step > self.next_decay and self.alpha > self.low_alpha_limit:
                 due = self.next_decay
                 self.decay_alpha()
-                self.next_decay = due + self.decay_step
+                # the reference's test `self.step > self.next_decay` (r_learning.py:293) first holds at step = due + 1, and
+                # decay_alpha then sets next_decay = step + decay_step (:259): the schedule slips by one episode per decay
+                self.next_decay = due + 1 + self.decay_step
             eng.td_steps(self.device_alpha(), chunk)
             if sync is not None:
                 sync.all_reduce()
             st = job_stats()
             self.step = base + st['episodes']
             self.top_score = max(self.top_score, st['best_score'])
-            self._collect_best_games(eng, seen, saving)
+            self._collect_best_games(eng, seen, saving and sync is None)
+            if sync is not None:
+                self._share_best_game(saving)
             top = max([t for t, cnt in enumerate(st['max_tile']) if cnt] or [0])
             if top > self.top_tile:
+                # r_learning.py:311-313 decays at every game that sets a new maximum tile; a chunk holds thousands of games, so
+                # every tile level above the old maximum that some game of the chunk ended on counts as one such game
+                levels = [t for t in range(self.top_tile + 1, top + 1) if st['max_tile'][t] - last['max_tile'][t] > 0] or [top]
                 self.top_tile = top
-                self.decay_alpha()
+                for _ in levels:
+                    self.decay_alpha()
+            last = st
             while self.step >= next100:
                 done = st['episodes'] - mark100['episodes']
                 ma = int((st['score_sum'] - mark100['score_sum']) / max(1, done))
@@ -547,6 +557,28 @@ class QAgent:
                 self._report_1000(self.step, average, [r * 1000 / max(1, done) for r in reached], None, time.time() - start, saving)
                 start, mark1000, next1000 = time.time(), dict(st), (self.step // 1000 + 1) * 1000
         self._finish(global_start, saving)
+        self.print = own_print                                # (a non-chief rank was silenced for the run only)
+
+    def _share_best_game(self, saving):
+        """Multi-rank run: every rank watches its own lanes; the best recorded game of the JOB becomes every rank's top_game
+        (the rank that holds it ships the Game), so that rank 0 saves a game that matches the job-wide bookkeeping."""
+        mine = self.top_game.score if self.top_game is not None else -1
+        scores = [None] * self.world
+        self._dist.all_gather_object(scores, int(mine))
+        owner = int(np.argmax(scores))
+        if scores[owner] < 0 or scores[owner] == getattr(self, '_shared_best', -1):
+            return
+        box = [self.top_game if self.rank == owner else None]
+        self._dist.broadcast_object_list(box, src=owner)
+        self._shared_best = scores[owner]
+        if self.rank != owner:
+            self.top_game = box[0]
+        if self.rank == 0:
+            if owner != 0:                                    # (rank 0's own games were announced by _collect_best_games)
+                self.print(f'\nnew best recorded game at episode {self.step} (played on rank {owner})!\n{self.top_game}\n')
+            if saving:
+                self.save_game(self.top_game)
+                self.print(f'game saved at {self.game_file}')
 
     # ---- evaluation harness (r_learning.py:348-406)
 

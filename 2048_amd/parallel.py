@@ -48,7 +48,7 @@ class EngineTable:
     def __init__(self, engine):
         self.e = engine
         self.slots = engine.slots
-        self.device = f'cuda:{engine.device}'
+        self.device = 'cpu' if getattr(engine, 'backend', 'hip') == 'cpu' else f'cuda:{engine.device}'
 
     def delta_begin(self):
         self.e.delta_begin()

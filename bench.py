@@ -497,6 +497,8 @@ def main():
             if torch.cuda.device_count():
                 local_rank = local_rank % torch.cuda.device_count()
                 torch.cuda.set_device(local_rank)
+            else:
+                local_rank = 0            # no GPU: only an explicit G2048_BACKEND=cpu gets further (the host is its device 0)
             dist.init_process_group(args.backend, timeout=limit)
         fault_inject(args.fault_inject, rank, 'init')
 
@@ -531,7 +533,8 @@ def main():
         if dist:
             import torch
             dist.barrier()
-            torch.cuda.synchronize()
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
 
     def max_over_ranks(x):
         if not dist:

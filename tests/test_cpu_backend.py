@@ -143,3 +143,73 @@ def test_threads_do_not_change_the_games(monkeypatch):
     a, b = out
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and a[4] == b[4]
     assert np.abs(a[3] - b[3]).max() <= 2e-7 * max(1.0, np.abs(a[3]).max())
+
+
+def test_qagent_train_run_two_ranks_on_the_cpu_backend(tmp_path):
+    """QAgent.train_run as a two-rank torch.distributed job (gloo), each rank a real Engine on the CPU backend: the ranks play
+    different lane shards, exchange their accumulated weight deltas every epoch through parallel.DeltaSync (the host-pointer
+    form of g2048_delta_*), stay identical replicas with identical schedules, agree on the job's best recorded game, and
+    rank 0 reports for the job.  The same script is the 8-GPU training entry point (tools/train_multi.py)."""
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    dump = str(tmp_path / 'rank')
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                   G2048_BACKEND='cpu', G2048_CPU_THREADS='2')
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, 'tools', 'train_multi.py'), '--n', '2', '--batch', '512', '--episodes', '4000',
+                                       '--epoch', '16', '--backend', 'gloo', '--comm', 'torch', '--dump', dump], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs[0][1][-1500:] + outs[1][1][-1500:]
+    a, b = (np.load(f'{dump}.{r}.npz') for r in range(2))
+    assert int(a['step']) == int(b['step']) >= 4000 and float(a['alpha']) == float(b['alpha']) and int(a['top_tile']) == int(b['top_tile'])
+    assert np.array_equal(a['history'], b['history']) and len(a['history']) > 5
+    assert np.array_equal(a['w_head'], b['w_head']) and np.array_equal(a['w_tail'], b['w_tail']) and float(a['wsum']) == float(b['wsum'])
+    assert int(a['reduces']) > 3 and str(a['sync']) == 'DeltaSync'
+    assert int(a['top_game_score']) == int(b['top_game_score']) > 0          # one best game for the whole job
+    assert int(a['top_game_score']) <= int(a['top_score'])
+    assert 'training session started' in outs[0][0] and 'on each of 2 GPUs' in outs[0][0] and 'training session started' not in outs[1][0]
+
+
+def _bench_cpu(*extra, timeout=300):
+    import json
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, G2048_BACKEND='cpu', G2048_CPU_THREADS='2')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        env.pop(k, None)
+    t0 = time.monotonic()
+    res = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--batch', '2048', '--n-tuple', '4', '--steps', '6',
+                          '--warmup', '2', '--condition', '4', '--epoch', '3', '--repeats', '1', '--no-cpu-baseline', '--trained-steps', '0', *extra],
+                         capture_output=True, text=True, timeout=timeout, env=env)
+    line = json.loads(res.stdout.strip().splitlines()[-1]) if res.returncode == 0 and res.stdout.strip() else None
+    return res, line, time.monotonic() - t0
+
+
+def test_bench_two_ranks_whole_path_on_the_cpu_backend():
+    """bench.py --gpus 2 end to end with real engines (CPU backend), gloo as transport: the self-launcher, lane sharding by rank,
+    the epoch loop, the native-path set-up protocol (no RCCL here: EVERY rank falls back to torch.distributed together), the
+    contract's JSON line with its comm block."""
+    res, line, _ = _bench_cpu('--comm', 'native')
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert line['n_gpus'] == 2 and line['steps'] == 6 and line['scaling'] == 'weak' and line['value'] > 0
+    assert line['comm']['nranks_seen'] == 2 and line['comm']['exchanges_per_timed_region'] == 2 and line['comm']['allreduce_plus_apply_ms'] > 0
+    assert 'torch.distributed all_reduce (gloo)' in line['comm']['kind'] and 'native RCCL path unavailable' in res.stderr
+    assert line['roofline']['frac'] <= 1.0 and 'invalid' not in line['roofline']
+
+
+def test_bench_rank_killed_mid_run_on_the_cpu_backend():
+    """One rank dies between two exchanges; the survivor would sit in the next all-reduce.  The parent ends the job within
+    seconds, exits non-zero and prints no result line."""
+    res, line, dt = _bench_cpu('--comm', 'torch', '--fault-inject', 'exit@1:run')
+    assert res.returncode != 0 and line is None and dt < 120
+    assert 'rank 1 exited with code 3' in res.stderr and res.stdout.strip() == ''

@@ -39,8 +39,11 @@ def main():
         torch.cuda.set_device(local)
         dist.init_process_group('nccl', device_id=torch.device('cuda', local))
     else:
-        local = local % torch.cuda.device_count()
-        torch.cuda.set_device(local)
+        if torch.cuda.device_count():
+            local = local % torch.cuda.device_count()
+            torch.cuda.set_device(local)
+        else:
+            local = 0                     # no GPU: the job runs on the CPU backend if G2048_BACKEND=cpu says so (explicitly)
         dist.init_process_group(args.backend)
     import game2048.r_learning as rl
     np.random.seed(2048)
@@ -51,7 +54,8 @@ def main():
         w = agent.engine.get_weights()
         np.savez(f'{args.dump}.{rank}.npz', step=agent.step, alpha=agent.alpha, top_tile=agent.top_tile, top_score=agent.top_score,
                  history=np.array(agent.train_history), wsum=float(w.astype(np.float64).sum()), w_head=w[:4096], w_tail=w[-4096:],
-                 sync=type(agent._sync).__name__, reduces=agent._sync.reduces if agent._sync else 0)
+                 sync=type(agent._sync).__name__, reduces=agent._sync.reduces if agent._sync else 0,
+                 top_game_score=agent.top_game.score if agent.top_game is not None else -1)
     dist.barrier()
     if hasattr(agent._sync, 'close'):
         agent._sync.close()
