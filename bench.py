@@ -235,9 +235,11 @@ def build_roofline(eng, n, B, ms_step, ms_play, ms_owner, ms_tail, ms_apply, st,
                             'achieved': l2, 'peak': L2_PEAK_GBS, 'unit': 'GB/s', 'frac': l2 / L2_PEAK_GBS})
     valu, cyc = pm('k_td_play', 'SQ_ACTIVE_INST_VALU'), pm('k_td_play', 'GRBM_GUI_ACTIVE')
     if valu is not None and cyc:
-        # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the chip's 1 024 SIMDs (MI355X_MICROARCH.md, PMC units)
-        busy = valu * 4.0 / 1024.0 / cyc
-        k['limits'].append({'bound': 'valu', 'what': 'SQ_ACTIVE_INST_VALU x 4 / 1024 SIMDs / GRBM_GUI_ACTIVE', 'busy_frac': busy})
+        # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the chip's 1 024 SIMDs (MI355X_MICROARCH.md, PMC units);
+        # GRBM_GUI_ACTIVE is the kernel's busy cycles summed over the 8 XCDs
+        busy = (valu * 4.0 / 1024.0) / (cyc / 8.0)
+        k['limits'].append({'bound': 'valu', 'what': '(SQ_ACTIVE_INST_VALU x 4 / 1 024 SIMDs) / (GRBM_GUI_ACTIVE / 8 XCDs): share of the kernel\'s cycles in which a SIMD issues VALU work',
+                            'achieved': busy, 'peak': 1.0, 'unit': 'busy fraction', 'frac': busy})
     hb = pm('k_td_play', 'hbm_bytes')
     if hb is not None:
         g = hb / (ms_play * 1e-3) / 1e9
