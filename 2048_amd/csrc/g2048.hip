@@ -342,6 +342,18 @@ __device__ __forceinline__ float ld_w(const float* __restrict__ w, uint32_t slot
 __device__ __forceinline__ float ld_w(const float* __restrict__ w, uint32_t slot) { return w[slot]; }
 #endif
 
+// the gather of feature f: the f_6 features' 361 MB of tables (n = 6, f >= 21) have next to no reuse in a CU's 32 KB L1
+#ifndef G2048_HEX_LOAD          // 0: plain load; 1: nontemporal (L1 bypass)
+#define G2048_HEX_LOAD 0
+#endif
+template <int N>
+__device__ __forceinline__ float ld_w_f(const float* __restrict__ w, uint32_t slot, int f) {
+#if G2048_HEX_LOAD == 1
+    if (N == 6 && f >= 21) return __builtin_nontemporal_load(w + slot);
+#endif
+    return ld_w(w, slot);
+}
+
 template <int N>
 __device__ __forceinline__ float value_of(const float* __restrict__ w, const Board& b) {
     constexpr int F = Shape<N>::F;
@@ -434,8 +446,8 @@ __device__ __forceinline__ Choice choose(const float* __restrict__ w, const Move
         memory_slots<N>(pack_board((MB).after), sb);                                \
         float xa[F], xb[F];                                                          \
         _Pragma("unroll") for (int f = 0; f < F; ++f) {                              \
-            xa[f] = ld_w(w, (MA).changed ? sa[f] : 0u);                              \
-            xb[f] = ld_w(w, (MB).changed ? sb[f] : 0u);                              \
+            xa[f] = ld_w_f<N>(w, (MA).changed ? sa[f] : 0u, f);                      \
+            xb[f] = ld_w_f<N>(w, (MB).changed ? sb[f] : 0u, f);                      \
         }                                                                            \
         float va = 0.0f, vb = 0.0f;                                                  \
         _Pragma("unroll") for (int f = 0; f < F; ++f) {                              \
@@ -546,6 +558,9 @@ __device__ __forceinline__ void load_hot_set(float* hot, const float* __restrict
 #define G2048_HOT_REGS1(M) M(0, "v185") M(1, "v186") M(2, "v187") M(3, "v188") M(4, "v189") M(5, "v190") M(6, "v191") M(7, "v192") M(8, "v193") M(9, "v194") M(10, "v195") M(11, "v196") M(12, "v197") M(13, "v198") M(14, "v199") M(15, "v200") M(16, "v201")
 #define G2048_HOT_REGS2(M) M(0, "v202") M(1, "v203") M(2, "v204") M(3, "v205") M(4, "v206") M(5, "v207") M(6, "v208") M(7, "v209") M(8, "v210") M(9, "v211") M(10, "v212") M(11, "v213") M(12, "v214") M(13, "v215") M(14, "v216") M(15, "v217") M(16, "v218")
 #define G2048_HOT_REGS3(M) M(0, "v219") M(1, "v220") M(2, "v221") M(3, "v222") M(4, "v223") M(5, "v224") M(6, "v225") M(7, "v226") M(8, "v227") M(9, "v228") M(10, "v229") M(11, "v230") M(12, "v231") M(13, "v232") M(14, "v233") M(15, "v234") M(16, "v235")
+#ifndef G2048_COLD_POLICY        // (experiment: cache policy of the cold gathers, e.g. " nt" or " sc1")
+#define G2048_COLD_POLICY ""
+#endif
 #define PLAY_HOT_WAVES_PER_EU 3           // the allocator owns 512 / 3 -> 168 VGPRs: v0 .. v167
 #define PLAY_HOT_LAST_VGPR "v235"
 
@@ -563,7 +578,7 @@ __device__ __forceinline__ Choice choose_hot(const float* __restrict__ w, const 
     // phase A + B of one direction: T[f] = the gather's place in its table (memory order), hot iff T[f] < HOT_PER_FEATURE
 #define G2048_HOT_LDS(f, reg) asm volatile("ds_read_b32 " reg ", %0" ::"v"(hot_base + (((uint32_t)(f) * HOT_PER_FEATURE + (T_[f] & (HOT_PER_FEATURE - 1u))) << 2)));
 #define G2048_HOT_GLB(f, reg) \
-    if (changed_ && T_[f] >= HOT_PER_FEATURE) asm volatile("global_load_dword " reg ", %0, %1" ::"v"(((uint32_t)(f) * 65536u + T_[f]) << 2), "s"(w));
+    if (changed_ && T_[f] >= HOT_PER_FEATURE) asm volatile("global_load_dword " reg ", %0, %1" G2048_COLD_POLICY ::"v"(((uint32_t)(f) * 65536u + T_[f]) << 2), "s"(w));
 #define G2048_HOT_DIR(M, REGS, XC)                                                          \
     float XC[F > 17 ? F - 17 : 1];                                                          \
     {                                                                                       \
@@ -586,10 +601,40 @@ __device__ __forceinline__ Choice choose_hot(const float* __restrict__ w, const 
         _Pragma("unroll") for (int f = 17; f < F; ++f) acc_ += XC[f - 17];                 \
         V = acc_;                                                                           \
     }
+#ifdef G2048_EXP_LDS_FIRST       // (experiment: all four directions' LDS reads, ONE wait, then all masked loads — 68 offsets stay live in between)
+#define G2048_HOT_PREP(M, OFF, CH, XC, MSV)                                                 \
+    uint32_t OFF[17], MSV[F > 17 ? F - 17 : 1];                                             \
+    const bool CH = (M).changed;                                                            \
+    {                                                                                       \
+        uint32_t s_[F], ms_[F];                                                             \
+        feature_slots<N>(pack_board((M).after), s_);                                        \
+        memory_slots<N>(pack_board((M).after), ms_);                                        \
+        _Pragma("unroll") for (int f = 0; f < 17; ++f) OFF[f] = bit_transpose16(s_[f] & 0xFFFFu); \
+        _Pragma("unroll") for (int f = 17; f < F; ++f) MSV[f - 17] = ms_[f];                \
+    }
+#define G2048_HOT_LDS2(f, reg) asm volatile("ds_read_b32 " reg ", %0" ::"v"(hot_base + (((uint32_t)(f) * HOT_PER_FEATURE + (T_[f] & (HOT_PER_FEATURE - 1u))) << 2)));
+    G2048_HOT_PREP(mv.m0, t0, ch0, xc0, q0)
+    G2048_HOT_PREP(mv.m1, t1, ch1, xc1, q1)
+    G2048_HOT_PREP(mv.m2, t2, ch2, xc2, q2)
+    G2048_HOT_PREP(mv.m3, t3, ch3, xc3, q3)
+    { const uint32_t* T_ = t0; G2048_HOT_REGS0(G2048_HOT_LDS2) }
+    { const uint32_t* T_ = t1; G2048_HOT_REGS1(G2048_HOT_LDS2) }
+    { const uint32_t* T_ = t2; G2048_HOT_REGS2(G2048_HOT_LDS2) }
+    { const uint32_t* T_ = t3; G2048_HOT_REGS3(G2048_HOT_LDS2) }
+    asm volatile("s_waitcnt lgkmcnt(0)");
+    float xc0[F > 17 ? F - 17 : 1], xc1[F > 17 ? F - 17 : 1], xc2[F > 17 ? F - 17 : 1], xc3[F > 17 ? F - 17 : 1];
+    { const uint32_t* T_ = t0; const bool changed_ = ch0; G2048_HOT_REGS0(G2048_HOT_GLB) _Pragma("unroll") for (int f = 17; f < F; ++f) xc0[f - 17] = ld_w(w, changed_ ? q0[f - 17] : 0u); }
+    { const uint32_t* T_ = t1; const bool changed_ = ch1; G2048_HOT_REGS1(G2048_HOT_GLB) _Pragma("unroll") for (int f = 17; f < F; ++f) xc1[f - 17] = ld_w(w, changed_ ? q1[f - 17] : 0u); }
+    { const uint32_t* T_ = t2; const bool changed_ = ch2; G2048_HOT_REGS2(G2048_HOT_GLB) _Pragma("unroll") for (int f = 17; f < F; ++f) xc2[f - 17] = ld_w(w, changed_ ? q2[f - 17] : 0u); }
+    { const uint32_t* T_ = t3; const bool changed_ = ch3; G2048_HOT_REGS3(G2048_HOT_GLB) _Pragma("unroll") for (int f = 17; f < F; ++f) xc3[f - 17] = ld_w(w, changed_ ? q3[f - 17] : 0u); }
+#undef G2048_HOT_PREP
+#undef G2048_HOT_LDS2
+#else
     G2048_HOT_DIR(mv.m0, G2048_HOT_REGS0, xc0)
     G2048_HOT_DIR(mv.m1, G2048_HOT_REGS1, xc1)
     G2048_HOT_DIR(mv.m2, G2048_HOT_REGS2, xc2)
     G2048_HOT_DIR(mv.m3, G2048_HOT_REGS3, xc3)
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     G2048_HOT_SUM(G2048_HOT_REGS0, xc0, v0)
     G2048_HOT_SUM(G2048_HOT_REGS1, xc1, v1)
