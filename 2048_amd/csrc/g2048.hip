@@ -3134,9 +3134,7 @@ int build_slices(g2048_ctx* c) {
         for (size_t k = 0; k < nc; ++k) {
             if (!in_lds[k]) continue;
             const double ideal = lds_total > 0 ? cost[k] / lds_total * budget : 8.0;
-            // (thin chunks that scan the 4-byte chunk ids are always placed flat: all of them read the same 4 MB id array, which
-            // stays resident wherever the workgroup runs, and an exact workgroup count balances better than a multiple of 8)
-            if (ideal < c->knob.plan_mixed || pref[k]) {
+            if (ideal < c->knob.plan_mixed) {
                 fparts[k] = std::max(min_flat, (uint32_t)(ideal + 0.999));
                 flat_wgs += fparts[k];
             } else {
