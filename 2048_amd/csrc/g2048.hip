@@ -904,21 +904,19 @@ struct TdRecs {
 // 2 bits per image for the four four-cell orbits (byte v = orbit v), 6 bits per image (a byte each) for the cross orbit.
 // A workgroup that owns a THIN chunk (a few per cent of its orbit's adds) scans these 4 bytes per record instead of the
 // 8 + 4 or 16 + 4 bytes of indices and dw, and fetches the indices of the few records that concern it (own_run, PREF).
+constexpr size_t OIDX_BYTES_PER_LANE = 4 * 8 + 16 + 4 + 4 + 2;
 constexpr uint32_t OIDX_CHUNK_SHIFT = 14;       // log2(FIXED_SLOTS): the chunk ids are valid for fixed-point chunks only
 struct OrbitIdx {
     uint2* q;       // [4][B]
     uint4* x;       // [B]
+    uint32_t* cq;   // [B] chunk ids of q
+    uint32_t* cx;   // [B] chunk ids of x
     uint16_t* c;    // [B]
-    uint32_t* cq;   // [B] chunk ids of q (16-byte aligned: scanned with 16-byte loads, 4 records each)
-    uint32_t* cx;   // [B] chunk ids of x (likewise)
 };
-__host__ __device__ __forceinline__ size_t oidx_align16(size_t bytes) { return (bytes + 15) & ~(size_t)15; }
-__host__ __device__ __forceinline__ size_t oidx_bytes(size_t B) { return oidx_align16(50 * B) + 2 * oidx_align16(4 * B); }
 __host__ __device__ __forceinline__ OrbitIdx orbit_idx(const uint8_t* base, size_t B) {
     uint8_t* b = const_cast<uint8_t*>(base);
-    const size_t o1 = oidx_align16(50 * B), o2 = o1 + oidx_align16(4 * B);
-    return OrbitIdx{reinterpret_cast<uint2*>(b), reinterpret_cast<uint4*>(b + 32 * B), reinterpret_cast<uint16_t*>(b + 48 * B),
-                    reinterpret_cast<uint32_t*>(b + o1), reinterpret_cast<uint32_t*>(b + o2)};
+    return OrbitIdx{reinterpret_cast<uint2*>(b), reinterpret_cast<uint4*>(b + 32 * B), reinterpret_cast<uint32_t*>(b + 48 * B),
+                    reinterpret_cast<uint32_t*>(b + 52 * B), reinterpret_cast<uint16_t*>(b + 56 * B)};
 }
 
 template <int N>
@@ -1655,27 +1653,29 @@ __device__ __forceinline__ void own_run(float* acc, const Slice& s, const TdRecs
                 if (recs.unit) dw = dw != 0.0f ? 1.0f : 0.0f;
                 own_accum_idx<NI, false, FIXED>(idx, dw, on && dw != 0.0f, acc, s, lo_rel, nhit_wave, D, Dc, fb_hits, (double)scale, cbits);
             };
-            // 16 bytes = the chunk ids of 4 consecutive records per load, the loads of TWO blocks in flight per thread: a scan is a
-            // latency-bound stream (one 1 024-thread workgroup per CU against ~2 us of L2 / Infinity-Cache latency), and 4-byte loads
-            // kept 16 KB in flight per CU against the plain scan's 48 KB.
-            static_assert(U == 4, "a thread takes 4 consecutive records of a 4 096-record block");
-            const uint4* const ids4 = reinterpret_cast<const uint4*>(ids);
-            auto sift = [&](const uint4& w4, uint32_t r0) {     // records r0 .. r0 + 3
-                const uint32_t w[4] = {w4.x, w4.y, w4.z, w4.w};
+            for (uint32_t blk = first; blk < nblk; blk += stride) {
+                const uint32_t base0 = blk * BLK;
+                uint32_t w[U];
 #pragma unroll
-                for (uint32_t j = 0; j < 4; ++j) {
+                for (int u = 0; u < U; ++u) {
+                    const uint32_t r = base0 + threadIdx.x + (uint32_t)u * OWN_WG;
+                    w[u] = ids[r < end ? r : end - 1];
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const uint32_t r = base0 + threadIdx.x + (uint32_t)u * OWN_WG;
                     bool m;
                     if constexpr (V < 4) {
-                        const uint32_t f = ((w[j] >> (8 * V)) & 0xFFu) ^ (my * 0x55u);       // a 2-bit field is zero where the image's chunk is mine
+                        const uint32_t f = ((w[u] >> (8 * V)) & 0xFFu) ^ (my * 0x55u);       // a 2-bit field is zero where the image's chunk is mine
                         m = (~(f | (f >> 1)) & 0x55u) != 0u;
                     } else {
-                        const uint32_t f = w[j] ^ (my * 0x01010101u);                        // a byte is zero where the image's chunk is mine
+                        const uint32_t f = w[u] ^ (my * 0x01010101u);                        // a byte is zero where the image's chunk is mine
                         m = ((f - 0x01010101u) & ~f & 0x80808080u) != 0u;
                     }
-                    m = m && r0 + j < end;
+                    m = m && r < end;
                     const uint64_t mask = __ballot(m);
                     if (mask) {
-                        if (m) wq[wn + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = r0 + j;
+                        if (m) wq[wn + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = r;
                         wn += (uint32_t)__popcll(mask);
                         if (wn >= 64u) {                        // (wn < 64 before, <= 64 added: the queue holds 128)
                             take(64u);
@@ -1685,15 +1685,6 @@ __device__ __forceinline__ void own_run(float* acc, const Slice& s, const TdRecs
                         }
                     }
                 }
-            };
-            const uint32_t last4 = (end + 3u) / 4u - 1u;        // (the arrays are padded to 16 bytes: the last load may reach 3 entries past `end`)
-            for (uint32_t blk = first; blk < nblk; blk += 2u * stride) {
-                const uint32_t ra = blk * BLK + 4u * threadIdx.x, rb = (blk + stride) * BLK + 4u * threadIdx.x;
-                const bool has_b = blk + stride < nblk;
-                const uint4 wa = ids4[ra / 4u < last4 ? ra / 4u : last4];
-                const uint4 wb = ids4[has_b && rb / 4u < last4 ? rb / 4u : last4];
-                sift(wa, ra);
-                if (has_b) sift(wb, rb);
             }
             if (wn) take(wn);
         } else
@@ -3621,7 +3612,7 @@ static int create_impl(int device, uint32_t batch, int n_tuple, uint64_t seed, u
         (rc = dalloc(c, &c->qcount, QCOUNT_WORDS)) || (rc = dalloc(c, &c->last_move, B)) || (rc = dalloc(c, &c->lane_id, B)) ||
         (rc = dalloc(c, &c->stats, 1)))
         return bail(rc);
-    if (n_tuple >= 4 && ((rc = dalloc(c, &c->oidx[0], oidx_bytes(B))) || (rc = dalloc(c, &c->oidx[1], oidx_bytes(B))))) return bail(rc);
+    if (n_tuple >= 4 && ((rc = dalloc(c, &c->oidx[0], OIDX_BYTES_PER_LANE * B)) || (rc = dalloc(c, &c->oidx[1], OIDX_BYTES_PER_LANE * B)))) return bail(rc);
     if (parent) {
         g2048_ctx* root = parent->parent ? parent->parent : parent;
         c->w = root->w;
