@@ -1606,7 +1606,7 @@ __device__ __forceinline__ void own_accum_idx(const uint32_t (&idx)[NI], float d
     }
 }
 
-constexpr uint32_t PREF_WAVE_QUEUE = 128, PREF_QUEUE = (OWN_WG / 64) * PREF_WAVE_QUEUE;       // thin chunks: every wave's queue of matching records (8 KB beside the 128 KB slice)
+constexpr uint32_t PREF_QUEUE = 6144;       // LDS queue of matching records (24 KB beside the 128 KB slice); drained when fewer than a block's worth of entries is free
 
 template <int N, int V, bool FB, bool FIXED, bool PREF = false>
 __device__ __forceinline__ void own_run(float* acc, const Slice& s, const TdRecs& recs, uint32_t B, uint32_t* hits, float* D, float* Dc,
@@ -1627,31 +1627,32 @@ __device__ __forceinline__ void own_run(float* acc, const Slice& s, const TdRecs
         const uint32_t per_xcd = s.xcd ? s.nparts >> 3 : 0u;
         const uint32_t first = s.xcd ? s.part / per_xcd + 8u * (s.part % per_xcd) : s.part, stride = s.xcd ? 8u * per_xcd : s.nparts;
         if constexpr (PREF && (V < 4 || V == 5)) {
-            // Thin chunk: most records have no index in this slice.  A wave reads 4 bytes per record — the chunk ids k_td_play left
-            // beside the indices — and queues the records with an image in THIS chunk in its own corner of LDS; whenever 64 are
-            // queued (and at the end) the wave fetches indices + dw of those records, one per lane, and adds them.  No barrier and
-            // no atomic on the way: the waves of the workgroup run on independently, as in the plain scan (a first version with one
-            // queue per workgroup and a barrier per block of records exposed every load's latency: 43 against 55 us per scan, and
-            // slower overall).  Same blocks, same XCD residency as the plain scan.
+            // Thin chunk: most records have no index in this slice.  Pass A reads 4 bytes per record — the chunk ids k_td_play left
+            // beside the indices — and queues the records with an image in THIS chunk; the queue is drained by the whole workgroup
+            // (indices + dw fetched for those records only) whenever it holds a drain's worth, and at the end.  Same blocks, same
+            // XCD residency as the plain scan.
             const uint32_t my = lo_rel >> OIDX_CHUNK_SHIFT;
             const uint32_t* const ids = V < 4 ? oi.cq : oi.cx;
             const uint32_t lane = threadIdx.x & 63u;
-            uint32_t* const wq = pq + (threadIdx.x >> 6) * PREF_WAVE_QUEUE;
-            uint32_t wn = 0;                                    // entries in the wave's queue (wave-uniform)
-            auto take = [&](uint32_t count) {                   // the first `count` (<= 64) queued records, one per lane
-                const bool on = lane < count;
-                const uint32_t r = wq[on ? lane : 0u];
-                uint32_t idx[NI];
-                if constexpr (V < 4) {
-                    const uint2 t = oi.q[(size_t)V * B + r];
-                    idx[0] = t.x & 0xFFFFu; idx[1] = t.x >> 16; idx[2] = t.y & 0xFFFFu; idx[3] = t.y >> 16;
-                } else {
-                    const uint4 t = oi.x[r];
-                    idx[0] = t.x; idx[1] = t.y; idx[2] = t.z; idx[3] = t.w;
+            auto drain = [&]() {
+                const uint32_t nq = *pqn;
+                for (uint32_t j = threadIdx.x; j < nq; j += OWN_WG) {
+                    const uint32_t r = pq[j];
+                    uint32_t idx[NI];
+                    if constexpr (V < 4) {
+                        const uint2 t = oi.q[(size_t)V * B + r];
+                        idx[0] = t.x & 0xFFFFu; idx[1] = t.x >> 16; idx[2] = t.y & 0xFFFFu; idx[3] = t.y >> 16;
+                    } else {
+                        const uint4 t = oi.x[r];
+                        idx[0] = t.x; idx[1] = t.y; idx[2] = t.z; idx[3] = t.w;
+                    }
+                    float dw = recs.dw1[r];
+                    if (recs.unit) dw = dw != 0.0f ? 1.0f : 0.0f;
+                    own_accum_idx<NI, false, FIXED>(idx, dw, dw != 0.0f, acc, s, lo_rel, nhit_wave, D, Dc, fb_hits, (double)scale, cbits);
                 }
-                float dw = recs.dw1[r];
-                if (recs.unit) dw = dw != 0.0f ? 1.0f : 0.0f;
-                own_accum_idx<NI, false, FIXED>(idx, dw, on && dw != 0.0f, acc, s, lo_rel, nhit_wave, D, Dc, fb_hits, (double)scale, cbits);
+                __syncthreads();
+                if (threadIdx.x == 0) *pqn = 0;
+                __syncthreads();
             };
             for (uint32_t blk = first; blk < nblk; blk += stride) {
                 const uint32_t base0 = blk * BLK;
@@ -1675,18 +1676,16 @@ __device__ __forceinline__ void own_run(float* acc, const Slice& s, const TdRecs
                     m = m && r < end;
                     const uint64_t mask = __ballot(m);
                     if (mask) {
-                        if (m) wq[wn + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = r;
-                        wn += (uint32_t)__popcll(mask);
-                        if (wn >= 64u) {                        // (wn < 64 before, <= 64 added: the queue holds 128)
-                            take(64u);
-                            const uint32_t rest = wn - 64u, moved = wq[64u + (lane < rest ? lane : 0u)];
-                            if (lane < rest) wq[lane] = moved;
-                            wn = rest;
-                        }
+                        uint32_t at = 0;
+                        if (lane == 0) at = atomicAdd(pqn, (uint32_t)__popcll(mask));
+                        at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
+                        if (m) pq[at + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = r;
                     }
                 }
+                __syncthreads();
+                if (*pqn > PREF_QUEUE - BLK) drain();       // (uniform: read behind the barrier)
             }
-            if (wn) take(wn);
+            drain();
         } else
         for (uint32_t blk = first; blk < nblk; blk += stride) {
             const uint32_t base0 = blk * BLK;
@@ -1795,7 +1794,8 @@ __global__ __launch_bounds__(OWN_WG) void k_td_update_owner(float* dst, float* c
                                                             uint64_t* wg_clock) {
     __shared__ float acc[OWN_SLOTS];
     __shared__ uint32_t fb_hits[64];
-    __shared__ uint32_t pq[N >= 4 ? PREF_QUEUE : 1];        // thin chunks: the waves' queues of records whose chunk ids matched (own_run, PREF)
+    __shared__ uint32_t pq[N >= 4 ? PREF_QUEUE : 1];        // thin chunks: the records whose chunk ids matched (own_run, PREF)
+    __shared__ uint32_t pqn;
     const Slice s = slices[blockIdx.x];
     if (threadIdx.x == 0) wg_clock[2 * blockIdx.x] = wall_clock64();    // feeds the planner; g2048_debug_owner_plan shows them
     const bool fixed = own_fixed(N, (int)s.variant) || s.fixed;
@@ -1820,8 +1820,9 @@ __global__ __launch_bounds__(OWN_WG) void k_td_update_owner(float* dst, float* c
     const uint32_t words = fixed ? 2 * s.size : s.size;        // a fixed-point slot is two LDS words
     for (uint32_t j = threadIdx.x; j < words; j += OWN_WG) acc[j] = 0.0f;
     if (threadIdx.x < 64) fb_hits[threadIdx.x] = 0;
+    if (threadIdx.x == 0) pqn = 0;
     __syncthreads();
-    own_dispatch<N, 0>(acc, s, recs, B, hits, dst, cdst, fb_hits, scale, cbits, pq, nullptr);
+    own_dispatch<N, 0>(acc, s, recs, B, hits, dst, cdst, fb_hits, scale, cbits, pq, &pqn);
     __syncthreads();
     if (threadIdx.x < 64 && fb_hits[threadIdx.x]) atomicAdd(&hits[s.chunk0 + threadIdx.x], fb_hits[threadIdx.x]);
     const unsigned long long cmask = (1ull << cbits) - 1ull;
