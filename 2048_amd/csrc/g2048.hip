@@ -900,23 +900,15 @@ struct TdRecs {
 // bytes per record (indices + dw) instead of re-deriving them from the 16-byte packed state.  Orbit-major, so that a
 // scan is one contiguous stream:  [4][B] uint2 (four 16-bit indices: outer line, inner line, corner square, edge square)
 // | [B] uint4 (four 20-bit cross indices) | [B] uint16 (centre square).
-// | [B] uint32 + [B] uint32 chunk ids (round 3): in which 16 384-slot chunk of its orbit table each of those indices falls —
-// 2 bits per image for the four four-cell orbits (byte v = orbit v), 6 bits per image (a byte each) for the cross orbit.
-// A workgroup that owns a THIN chunk (a few per cent of its orbit's adds) scans these 4 bytes per record instead of the
-// 8 + 4 or 16 + 4 bytes of indices and dw, and fetches the indices of the few records that concern it (own_run, PREF).
-constexpr size_t OIDX_BYTES_PER_LANE = 4 * 8 + 16 + 4 + 4 + 2;
-constexpr uint32_t OIDX_CHUNK_SHIFT = 14;       // log2(FIXED_SLOTS): the chunk ids are valid for fixed-point chunks only
+constexpr size_t OIDX_BYTES_PER_LANE = 4 * 8 + 16 + 2;
 struct OrbitIdx {
     uint2* q;       // [4][B]
     uint4* x;       // [B]
-    uint32_t* cq;   // [B] chunk ids of q
-    uint32_t* cx;   // [B] chunk ids of x
     uint16_t* c;    // [B]
 };
 __host__ __device__ __forceinline__ OrbitIdx orbit_idx(const uint8_t* base, size_t B) {
     uint8_t* b = const_cast<uint8_t*>(base);
-    return OrbitIdx{reinterpret_cast<uint2*>(b), reinterpret_cast<uint4*>(b + 32 * B), reinterpret_cast<uint32_t*>(b + 48 * B),
-                    reinterpret_cast<uint32_t*>(b + 52 * B), reinterpret_cast<uint16_t*>(b + 56 * B)};
+    return OrbitIdx{reinterpret_cast<uint2*>(b), reinterpret_cast<uint4*>(b + 32 * B), reinterpret_cast<uint16_t*>(b + 48 * B)};
 }
 
 template <int N>
@@ -940,15 +932,6 @@ __device__ __forceinline__ void store_orbit_indices(uint8_t* base, uint32_t B, u
     for (int v = 0; v < 4; ++v) o.q[(size_t)v * B + i] = make_uint2(idx[v][0] | idx[v][1] << 16, idx[v][2] | idx[v][3] << 16);
     o.c[i] = (uint16_t)idx[4][0];
     if (N >= 5) o.x[i] = make_uint4(idx[5][0], idx[5][1], idx[5][2], idx[5][3]);
-    uint32_t cq = 0, cx = 0;
-#pragma unroll
-    for (int v = 0; v < 4; ++v)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) cq |= (idx[v][j] >> OIDX_CHUNK_SHIFT) << (8 * v + 2 * j);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) cx |= (idx[5][j] >> OIDX_CHUNK_SHIFT) << (8 * j);       // (n = 4: no cross orbit, idx[5] stays 0)
-    o.cq[i] = cq;
-    o.cx[i] = cx;
 }
 
 __device__ __forceinline__ void push_terminal(const TdRecs& r, const Packed& state, float dw) {
@@ -1392,7 +1375,6 @@ struct Slice {
     uint32_t cshift;        // log2 of the slots per chunk of this orbit table (OWN_SLOTS, or OWN_SLOTS / 2 for the fixed-point orbits)
     uint32_t fixed;         // 1: this workgroup sums in 64-bit fixed point (own_fixed, or every variant under the one-pass mean rule)
     uint32_t xcd;           // 1: XCD-resident plan — part = x * (nparts / 8) + j scans the record blocks b = x + 8 * (j + (nparts / 8) * t)
-    uint32_t pref;          // 1: thin chunk — scan the records' 4-byte chunk ids and fetch the indices of the matching records only (own_run, PREF)
 };
 
 // Symmetry orbits (n >= 4).  QAgent.update adds dw at f_i(g.x) for all 8 images g (r_learning.py:207-214).  Features
@@ -1606,11 +1588,9 @@ __device__ __forceinline__ void own_accum_idx(const uint32_t (&idx)[NI], float d
     }
 }
 
-constexpr uint32_t PREF_QUEUE = 6144;       // LDS queue of matching records (24 KB beside the 128 KB slice); drained when fewer than a block's worth of entries is free
-
-template <int N, int V, bool FB, bool FIXED, bool PREF = false>
+template <int N, int V, bool FB, bool FIXED>
 __device__ __forceinline__ void own_run(float* acc, const Slice& s, const TdRecs& recs, uint32_t B, uint32_t* hits, float* D, float* Dc,
-                                        uint32_t* fb_hits, float scale, uint32_t cbits, uint32_t* pq = nullptr, uint32_t* pqn = nullptr) {
+                                        uint32_t* fb_hits, float scale, uint32_t cbits) {
     constexpr int F0 = OwnVariants<N>::f0(V), FC = OwnVariants<N>::fc(V);
     constexpr uint32_t IMAGES = N >= 4 ? COSET_MASK[V < 6 ? V : 0] : 0xFFu;
     uint32_t nhit = 0, nhit_wave = 0;
@@ -1626,67 +1606,6 @@ __device__ __forceinline__ void own_run(float* acc, const Slice& s, const TdRecs
         const uint32_t nblk = (B + BLK - 1) / BLK, end = B;
         const uint32_t per_xcd = s.xcd ? s.nparts >> 3 : 0u;
         const uint32_t first = s.xcd ? s.part / per_xcd + 8u * (s.part % per_xcd) : s.part, stride = s.xcd ? 8u * per_xcd : s.nparts;
-        if constexpr (PREF && (V < 4 || V == 5)) {
-            // Thin chunk: most records have no index in this slice.  Pass A reads 4 bytes per record — the chunk ids k_td_play left
-            // beside the indices — and queues the records with an image in THIS chunk; the queue is drained by the whole workgroup
-            // (indices + dw fetched for those records only) whenever it holds a drain's worth, and at the end.  Same blocks, same
-            // XCD residency as the plain scan.
-            const uint32_t my = lo_rel >> OIDX_CHUNK_SHIFT;
-            const uint32_t* const ids = V < 4 ? oi.cq : oi.cx;
-            const uint32_t lane = threadIdx.x & 63u;
-            auto drain = [&]() {
-                const uint32_t nq = *pqn;
-                for (uint32_t j = threadIdx.x; j < nq; j += OWN_WG) {
-                    const uint32_t r = pq[j];
-                    uint32_t idx[NI];
-                    if constexpr (V < 4) {
-                        const uint2 t = oi.q[(size_t)V * B + r];
-                        idx[0] = t.x & 0xFFFFu; idx[1] = t.x >> 16; idx[2] = t.y & 0xFFFFu; idx[3] = t.y >> 16;
-                    } else {
-                        const uint4 t = oi.x[r];
-                        idx[0] = t.x; idx[1] = t.y; idx[2] = t.z; idx[3] = t.w;
-                    }
-                    float dw = recs.dw1[r];
-                    if (recs.unit) dw = dw != 0.0f ? 1.0f : 0.0f;
-                    own_accum_idx<NI, false, FIXED>(idx, dw, dw != 0.0f, acc, s, lo_rel, nhit_wave, D, Dc, fb_hits, (double)scale, cbits);
-                }
-                __syncthreads();
-                if (threadIdx.x == 0) *pqn = 0;
-                __syncthreads();
-            };
-            for (uint32_t blk = first; blk < nblk; blk += stride) {
-                const uint32_t base0 = blk * BLK;
-                uint32_t w[U];
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const uint32_t r = base0 + threadIdx.x + (uint32_t)u * OWN_WG;
-                    w[u] = ids[r < end ? r : end - 1];
-                }
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const uint32_t r = base0 + threadIdx.x + (uint32_t)u * OWN_WG;
-                    bool m;
-                    if constexpr (V < 4) {
-                        const uint32_t f = ((w[u] >> (8 * V)) & 0xFFu) ^ (my * 0x55u);       // a 2-bit field is zero where the image's chunk is mine
-                        m = (~(f | (f >> 1)) & 0x55u) != 0u;
-                    } else {
-                        const uint32_t f = w[u] ^ (my * 0x01010101u);                        // a byte is zero where the image's chunk is mine
-                        m = ((f - 0x01010101u) & ~f & 0x80808080u) != 0u;
-                    }
-                    m = m && r < end;
-                    const uint64_t mask = __ballot(m);
-                    if (mask) {
-                        uint32_t at = 0;
-                        if (lane == 0) at = atomicAdd(pqn, (uint32_t)__popcll(mask));
-                        at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
-                        if (m) pq[at + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = r;
-                    }
-                }
-                __syncthreads();
-                if (*pqn > PREF_QUEUE - BLK) drain();       // (uniform: read behind the barrier)
-            }
-            drain();
-        } else
         for (uint32_t blk = first; blk < nblk; blk += stride) {
             const uint32_t base0 = blk * BLK;
             uint32_t idx[U][NI];
@@ -1758,19 +1677,13 @@ __device__ __forceinline__ void own_run(float* acc, const Slice& s, const TdRecs
 
 template <int N, int V>
 __device__ __forceinline__ void own_dispatch(float* acc, const Slice& s, const TdRecs& recs, uint32_t B, uint32_t* hits, float* D, float* Dc,
-                                             uint32_t* fb_hits, float scale, uint32_t cbits, uint32_t* pq, uint32_t* pqn) {
+                                             uint32_t* fb_hits, float scale, uint32_t cbits) {
     if constexpr (V < OwnVariants<N>::COUNT) {
         if (s.variant == (uint32_t)V) {
             // the fallback duty (global atomics for chunks nobody holds in LDS) is carried by few workgroups: two
             // instantiations keep its tests out of everybody else's inner loop.  A variant that own_fixed leaves in fp32
             // (the cross orbit) also exists in fixed point: the one-pass mean rule needs the packed counts.
             const bool fb = N >= 4 && s.fb_mask;
-            if constexpr (N >= 4 && (V < 4 || V == 5)) {
-                if (s.pref && !fb && (own_fixed(N, V) || s.fixed)) {
-                    own_run<N, V, false, true, true>(acc, s, recs, B, hits, D, Dc, fb_hits, scale, cbits, pq, pqn);
-                    return;
-                }
-            }
             if (own_fixed(N, V) || s.fixed) {
                 if (fb)
                     own_run<N, V, true, true>(acc, s, recs, B, hits, D, Dc, fb_hits, scale, cbits);
@@ -1783,7 +1696,7 @@ __device__ __forceinline__ void own_dispatch(float* acc, const Slice& s, const T
                     own_run<N, V, false, false>(acc, s, recs, B, hits, D, Dc, fb_hits, scale, cbits);
             }
         } else
-            own_dispatch<N, V + 1>(acc, s, recs, B, hits, D, Dc, fb_hits, scale, cbits, pq, pqn);
+            own_dispatch<N, V + 1>(acc, s, recs, B, hits, D, Dc, fb_hits, scale, cbits);
     }
 }
 
@@ -1794,8 +1707,6 @@ __global__ __launch_bounds__(OWN_WG) void k_td_update_owner(float* dst, float* c
                                                             uint64_t* wg_clock) {
     __shared__ float acc[OWN_SLOTS];
     __shared__ uint32_t fb_hits[64];
-    __shared__ uint32_t pq[N >= 4 ? PREF_QUEUE : 1];        // thin chunks: the records whose chunk ids matched (own_run, PREF)
-    __shared__ uint32_t pqn;
     const Slice s = slices[blockIdx.x];
     if (threadIdx.x == 0) wg_clock[2 * blockIdx.x] = wall_clock64();    // feeds the planner; g2048_debug_owner_plan shows them
     const bool fixed = own_fixed(N, (int)s.variant) || s.fixed;
@@ -1820,9 +1731,8 @@ __global__ __launch_bounds__(OWN_WG) void k_td_update_owner(float* dst, float* c
     const uint32_t words = fixed ? 2 * s.size : s.size;        // a fixed-point slot is two LDS words
     for (uint32_t j = threadIdx.x; j < words; j += OWN_WG) acc[j] = 0.0f;
     if (threadIdx.x < 64) fb_hits[threadIdx.x] = 0;
-    if (threadIdx.x == 0) pqn = 0;
     __syncthreads();
-    own_dispatch<N, 0>(acc, s, recs, B, hits, dst, cdst, fb_hits, scale, cbits, pq, &pqn);
+    own_dispatch<N, 0>(acc, s, recs, B, hits, dst, cdst, fb_hits, scale, cbits);
     __syncthreads();
     if (threadIdx.x < 64 && fb_hits[threadIdx.x]) atomicAdd(&hits[s.chunk0 + threadIdx.x], fb_hits[threadIdx.x]);
     const unsigned long long cmask = (1ull << cbits) - 1ull;
@@ -2385,8 +2295,6 @@ __global__ __launch_bounds__(WG) void k_restore_order(LaneSet in, LaneSet out, C
 #pragma unroll
         for (int v = 0; v < 4; ++v) b.q[(size_t)v * B + id] = a.q[(size_t)v * B + j];
         b.x[id] = a.x[j];
-        b.cq[id] = a.cq[j];
-        b.cx[id] = a.cx[j];
         b.c[id] = a.c[j];
     }
 }
@@ -2555,8 +2463,6 @@ struct g2048_ctx {
         uint32_t play_dynamic = 2;      // full rounds of k_td_play's lane blocks left to the counter (besides the last, partial one)
         uint32_t sort_every = 16;       // default of g2048_set_lane_sort for new contexts (G2048_SORT_EVERY); 0 = never
         uint32_t sort_min_batch = 1u << 17;     // smaller batches keep their lane order
-        int own_prefilter = 1;          // thin chunks of the LDS-owner update scan the records' chunk ids first (G2048_OWN_PREFILTER)
-        double pref_share = 0.30;       // ... a chunk is thin below this share of its orbit's adds (G2048_PREF_SHARE)
         uint32_t sort_tile = SORT_TILE; // key bit of a cell: tile above 2^this (G2048_SORT_TILE)
         uint32_t sort_lag = 2;          // steps between the boards a sort looks at and the step that applies it (G2048_SORT_LAG; 0 = sort in line)
         int hex_bins = 1;               // n = 6: f_6 orbits through k_hex_* (0: k_td_update_tail's scattered atomics)
@@ -2658,8 +2564,6 @@ void read_knobs(g2048_ctx* c) {
     if (const char* e = getenv("G2048_SORT_EVERY")) k.sort_every = (uint32_t)atoi(e);
     if (const char* e = getenv("G2048_SORT_MIN")) k.sort_min_batch = (uint32_t)atoi(e);
     if (const char* e = getenv("G2048_SORT_LAG")) k.sort_lag = (uint32_t)atoi(e);
-    if (const char* e = getenv("G2048_OWN_PREFILTER")) k.own_prefilter = atoi(e);
-    if (const char* e = getenv("G2048_PREF_SHARE")) k.pref_share = atof(e);
     if (const char* e = getenv("G2048_SORT_TILE")) k.sort_tile = (uint32_t)atoi(e) < 15u ? (uint32_t)atoi(e) : 15u;
     if (const char* e = getenv("G2048_DELTA_ACCUM")) k.delta_accum = atoi(e);
     if (const char* e = getenv("G2048_PLAY_HOT_MIN")) k.play_hot_min = (uint32_t)atoi(e);
@@ -3053,17 +2957,6 @@ int build_slices(g2048_ctx* c) {
                     duty[best] |= 1ull << (j - k0);
                 }
         }
-    // thin chunks — in LDS, no fallback duty, a small share of their orbit's adds — scan the records' chunk ids first (own_run, PREF)
-    std::vector<char> pref(nc, 0);
-    if (c->n >= 4 && c->knob.own_prefilter && c->B >= 4096)
-        for (size_t k0 = 0; k0 < nc; k0 += chunks[k0].orb_chunks) {
-            const size_t cnt = chunks[k0].orb_chunks;
-            double orbit_total = 0;
-            for (size_t j = k0; j < k0 + cnt; ++j) orbit_total += c->load[j];
-            for (size_t j = k0; j < k0 + cnt; ++j)
-                pref[j] = in_lds[j] && !duty[j] && chunks[j].variant != 4 && chunks[j].size == FIXED_SLOTS && chunk_fixed(c, (int)chunks[j].variant) &&
-                          c->load[j] < c->knob.pref_share * orbit_total;
-        }
     std::vector<double> cost(nc, 0.0);
     double total = 0;
     size_t n_lds = 0;
@@ -3072,7 +2965,7 @@ int build_slices(g2048_ctx* c) {
         if (in_lds[k]) {
             // an add costs ~12x less where the sums are 64-bit fixed point (ds_add_u64) than where they are fp32 (ds_add_f32)
             const double per_add = (c->n >= 4 && chunk_fixed(c, (int)chunks[k].variant)) ? add_cost * fixed_ratio : add_cost;
-            cost[k] = (pref[k] ? 0.4 : 1.0) * chunks[k].scan * B + per_add * c->load[k];       // (a chunk-id scan: 4 bytes and a few instructions per record)
+            cost[k] = chunks[k].scan * B + per_add * c->load[k];
             total += cost[k];
             ++n_lds;
         }
@@ -3100,7 +2993,7 @@ int build_slices(g2048_ctx* c) {
     auto slice_of = [&](size_t k, uint32_t p, uint32_t np) {
         return Slice{chunks[k].variant, chunks[k].tlo, chunks[k].size, chunks[k].dlo, p, np, (uint32_t)k,
                      chunks[k].orb_tlo, chunks[k].orb_dlo, chunks[k].chunk0, duty[k], chunks[k].size >= OWN_SLOTS ? 15u : 14u,
-                     chunk_fixed(c, (int)chunks[k].variant) ? 1u : 0u, 0u, pref[k] ? 1u : 0u};
+                     chunk_fixed(c, (int)chunks[k].variant) ? 1u : 0u, 0u};
     };
     // 0: flat plan; 1 (default where it applies): XCD-resident scan.  (Cutting the chunks into pieces packed onto the 32
     // workgroups of an XCD, a workgroup running its pieces one after the other, was tried: 0.296 -> 0.311 ms per step.)
@@ -4132,7 +4025,7 @@ int g2048_debug_owner_plan(g2048_ctx* c, uint64_t* out, uint32_t capacity, uint3
         if (int rc = d2h(c, clk.data(), c->wg_clock, clk.size() * 8)) return rc;
     for (uint32_t i = 0; i < n; ++i) {
         const Slice& s = c->plan[i];
-        out[6 * i + 0] = s.variant | ((uint64_t)s.pref << 32);      // (bit 32: the workgroup scans chunk ids first)
+        out[6 * i + 0] = s.variant;
         out[6 * i + 1] = s.chunk;
         out[6 * i + 2] = s.part;
         out[6 * i + 3] = s.nparts;

@@ -254,12 +254,11 @@ def build_roofline(eng, n, B, ms_step, ms_play, ms_owner, ms_tail, ms_apply, st,
         rec_bytes = {0: 12, 1: 12, 2: 12, 3: 12, 4: 6, 5: 20} if n >= 4 else {}
         scans = {}
         for row in plan:
-            scans[(int(row[0]) & 0xFF, int(row[1]))] = int(row[0]) >> 32      # bit 32: a thin chunk, scanned through 4-byte chunk ids
-        scanned = sum((4 if thin else (rec_bytes.get(v, 20) if n >= 4 else 20)) * B for (v, _), thin in scans.items())
-        k['chunk_scans'] = {'plain': sum(1 for t in scans.values() if not t), 'chunk_ids_first': sum(1 for t in scans.values() if t)}
+            scans[(int(row[0]), int(row[1]))] = 1
+        scanned = sum((rec_bytes.get(v, 20) if n >= 4 else 20) * B for (v, _) in scans)
         if scanned and ms_owner > 0:
             g = scanned / (ms_owner * 1e-3) / 1e9
-            k['limits'].append({'bound': 'l2', 'what': f'{len(scans)} chunk scans of the step\'s records (8 + 4, 16 + 4 or 2 + 4 bytes per record and scan; 4 bytes where a thin chunk scans the chunk ids first, its few matches not counted), L2 / Infinity-Cache resident',
+            k['limits'].append({'bound': 'l2', 'what': f'{len(scans)} chunk scans of the step\'s records (8 + 4, 16 + 4 or 2 + 4 bytes per record and scan), L2 / Infinity-Cache resident',
                                 'bytes_per_launch': scanned, 'achieved': g, 'peak': L2_PEAK_GBS, 'unit': 'GB/s', 'frac': g / L2_PEAK_GBS})
     except Exception as e:
         k['plan_error'] = repr(e)

@@ -162,8 +162,7 @@ int g2048_td_steps_profiled(g2048_ctx* ctx, float alpha, uint32_t nsteps, float*
 int g2048_td_steps_kernel_ms(g2048_ctx* ctx, float alpha, uint32_t nsteps, float* out4);
 
 /* Diagnostics of the LDS-owner update (update mode 1): for each workgroup of the current plan six words
- * {orbit variant (bit 32 set: a thin chunk, scanned through the records' chunk ids), chunk, part, nparts, start clock,
- * end clock} of its last launch (clock: 100 MHz constant counter).
+ * {orbit variant, chunk, part, nparts, start clock, end clock} of its last launch (clock: 100 MHz constant counter).
  * No reference counterpart. */
 int g2048_debug_owner_plan(g2048_ctx* ctx, uint64_t* out, uint32_t capacity, uint32_t* count);
 /* what every lane did in the latest TD step — the entries Game.moves / Game.tiles get in QAgent.episode

@@ -355,34 +355,6 @@ def test_td_hot_set_path_vs_oracle(n, B, monkeypatch):
     eng.close()
 
 
-@pytest.mark.parametrize('rule', ['sum', 'mean'])
-@pytest.mark.parametrize('n,B', [(4, 4096), (5, 9001), (6, 4500)])
-def test_td_owner_chunk_id_scans_vs_oracle(n, B, rule, monkeypatch):
-    """The LDS-owner update's thin-chunk path (own_run, PREF): a workgroup scans the 4-byte chunk ids k_td_play leaves beside the
-    orbit indices, queues the records with an image in its chunk and fetches indices + dw for those only.  Forced on for EVERY
-    eligible chunk (G2048_PREF_SHARE above 1, G2048_PLAN_THR 0 so that every chunk sits in LDS) on boards whose tiles spread the
-    adds over many chunks — mid-game boards, then random boards of tiles 0..13; every step against the float64 oracle."""
-    monkeypatch.setenv('G2048_PREF_SHARE', '2.0')
-    monkeypatch.setenv('G2048_PLAN_THR', '0')
-    eng = Engine(B, n=n, seed=950 + n)
-    eng.set_auto_reset(False)
-    if rule == 'mean':
-        eng.set_update_rule(1)
-    eng.step_random(60)
-    for t in range(3):
-        helpers.check_td_step(eng, n, formulas.exact_alpha(n), formulas.weights(n, scale=2.0 ** -(4 + t)), rule=rule)
-    plan = eng.debug_owner_plan().astype(np.uint64)
-    assert ((plan[:, 0] >> np.uint64(32)) & np.uint64(1)).sum() > 0          # the path was in use
-    r = np.random.RandomState(n)
-    boards = (r.randint(0, 14, (B, 4, 4)) * (r.rand(B, 4, 4) < 0.8)).astype(np.uint8)
-    boards[:, 0, 0] = 0
-    boards[:, 1, 1] = np.maximum(boards[:, 1, 1], 1)
-    eng.set_boards(boards)
-    for t in range(3):
-        helpers.check_td_step(eng, n, formulas.exact_alpha(n), formulas.weights(n, scale=2.0 ** -(5 + t)), rule=rule)
-    eng.close()
-
-
 @pytest.mark.parametrize('lag', [2, 0])
 @pytest.mark.parametrize('n', [4, 5, 6])
 def test_lane_sort_is_invisible(n, lag, monkeypatch):

@@ -17,8 +17,6 @@ for rep in range(int(os.environ.get("REPS", 2))):
     print(f'steady: play {a:.3f} update {b:.3f} ms')
     eng.sync()
     t = eng.debug_owner_plan().astype(np.int64)
-    thin = t[:, 0] >> 32
-    t[:, 0] &= 0xFF
     t0 = t[:, 4].min()
     start, end = (t[:, 4] - t0) / 100.0, (t[:, 5] - t0) / 100.0        # microseconds
     print(f'{len(t)} workgroups; first start 0, last start {start.max():.1f} us, last end {end.max():.1f} us; mean duration {(end - start).mean():.1f} us')
@@ -26,7 +24,7 @@ for rep in range(int(os.environ.get("REPS", 2))):
         for ch in sorted(set(t[t[:, 0] == v, 1])):
             m = (t[:, 0] == v) & (t[:, 1] == ch)
             d = (end - start)[m]
-            print(f'  variant {v} chunk {ch:3d}{" (ids)" if thin[m][0] else "      "}: {m.sum():3d} wgs (nparts {t[m, 3][0]}), duration min {d.min():6.1f} mean {d.mean():6.1f} max {d.max():6.1f} us, start max {start[m].max():5.1f}, end max {end[m].max():6.1f}')
+            print(f'  variant {v} chunk {ch:3d}: {m.sum():3d} wgs (nparts {t[m, 3][0]}), duration min {d.min():6.1f} mean {d.mean():6.1f} max {d.max():6.1f} us, start max {start[m].max():5.1f}, end max {end[m].max():6.1f}')
     x = np.arange(len(t)) % 8
     print('  mean duration by blockIdx % 8 (XCD):', ' '.join(f'{(end - start)[x == k].mean():.1f}' for k in range(8)))
     print('  mean duration by record range (part * 8 // nparts):', ' '.join(f'{(end - start)[(t[:, 2] * 8 // t[:, 3]) == k].mean():.1f}' for k in range(8)))
