@@ -83,6 +83,19 @@ void hc_coset_masks(int32_t* reps, uint32_t* masks) {
     masks[6] = HEX_COSET_MASK[0]; masks[7] = HEX_COSET_MASK[1];
 }
 
+// n = 2, 3: the orbit representatives and coset masks the LDS-owner update uses (SmallOrbits<N>, features.hpp)
+int hc_small_orbits(int n, int32_t* reps, uint32_t* masks) {
+    if (n == 2) {
+        for (int o = 0; o < SmallOrbits<2>::COUNT; ++o) { reps[o] = SmallOrbits<2>::rep(o); masks[o] = SmallOrbits<2>::mask(o); }
+        return SmallOrbits<2>::COUNT;
+    }
+    if (n == 3) {
+        for (int o = 0; o < SmallOrbits<3>::COUNT; ++o) { reps[o] = SmallOrbits<3>::rep(o); masks[o] = SmallOrbits<3>::mask(o); }
+        return SmallOrbits<3>::COUNT;
+    }
+    return -1;
+}
+
 // out[count][8][F] flat slots of every feature of every D4 image
 int hc_image_slots(int n, const uint8_t* boards, int64_t count, int32_t* out) {
     for (int64_t i = 0; i < count; ++i) {

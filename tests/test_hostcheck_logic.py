@@ -122,6 +122,59 @@ def test_feature_slots_of_all_images(hc, golden, n):
         assert np.array_equal(out[:, gi, :], rb.slots(n, img))
 
 
+@pytest.mark.parametrize('n', [2, 3])
+def test_small_orbits_cover_every_add_of_the_reference_update(hc, n):
+    """n = 2, 3 (round 3): QAgent.update adds dw at f_i(g.x) for all 8 images g and all features i (r_learning.py:207-214).
+    The orbit-reduced update visits, for each orbit representative r, one image per coset of r's stabiliser (SmallOrbits<N>);
+    the apply kernel then hands the orbit table to every member feature through a digit permutation and symmetrises over the
+    stabiliser.  Checked here by brute force on random boards: (1) the representatives are exactly the first members of the
+    D4 orbits of the features; (2) folding the visited images with the stabiliser reproduces the multiset of all 8 images'
+    indices of the representative; (3) every feature's indices over the 8 images are a digit permutation of its
+    representative's — together: every one of the 8 x F adds of the reference is accounted for, once."""
+    F, nd = (24, 2) if n == 2 else (52, 3)
+    reps = np.zeros(8, np.int32)
+    masks = np.zeros(8, np.uint32)
+    count = hc.hc_small_orbits(n, ptr(reps), ptr(masks))
+    assert count == (4 if n == 2 else 8)
+    rng = np.random.default_rng(11)
+    boards = rng.integers(0, 16, size=(96, 16)).astype(np.uint8)
+    out = np.zeros((len(boards), 8, F), np.int32)
+    assert hc.hc_image_slots(n, ptr(boards), ctypes.c_int64(len(boards)), ptr(out)) == 0
+    idx = out - (np.arange(F) * 16 ** nd)[None, None, :]
+    digits = np.stack([(idx // 16 ** p) % 16 for p in range(nd)], axis=-1)             # [B, 8, F, nd]
+
+    def match(a, b):                                                                     # perm with a[:, p] == b[:, perm[p]] on every board
+        perm, used = [], set()
+        for p in range(nd):
+            q = next((q for q in range(nd) if q not in used and np.array_equal(a[:, p], b[:, q])), None)
+            if q is None:
+                return None
+            perm.append(q)
+            used.add(q)
+        return perm
+
+    found, member_of = [], {}
+    for i in range(F):
+        home = next((r for r in found if any(match(digits[:, 0, i], digits[:, g, r]) is not None for g in range(8))), None)
+        if home is None:
+            found.append(i)
+            home = i
+        member_of[i] = home
+    assert found == reps[:count].tolist()
+    adds = 0
+    for o in range(count):
+        r, mask = int(reps[o]), int(masks[o])
+        stab = [pm for pm in (match(digits[:, 0, r], digits[:, g, r]) for g in range(8)) if pm is not None]
+        images = [g for g in range(8) if (mask >> g) & 1]
+        assert len(stab) * len(images) == 8
+        folded = np.stack([sum(digits[:, g, r, pm[p]] * 16 ** p for p in range(nd)) for g in images for pm in stab], axis=1)
+        assert np.array_equal(np.sort(folded, axis=1), np.sort(idx[:, :, r], axis=1))
+        members = [i for i in range(F) if member_of[i] == r]
+        assert len(members) * len(stab) == 8                                             # orbit-stabiliser
+        adds += len(images)
+    assert adds == (24 if n == 2 else 52)                                                # instead of 8 x 24 = 192 / 8 x 52 = 416
+
+
 def test_coset_masks_reproduce_the_eight_images(hc):
     """QAgent.update adds dw at f(g.x) for all 8 images g (r_learning.py:207-214).  The update kernels visit, for the
     representative feature of each symmetry orbit, only the images of COSET_MASK and let the digit permutations of the
