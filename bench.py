@@ -99,9 +99,13 @@ def cpu_baseline(n, seconds):
 def cpu_ref_lines(pkg, n, seconds=4.0, batch=4096):
     """The stronger CPU line: the build's own C++ backend behind the same C ABI
     (lib2048_cpu.so, 2048_amd/csrc/cpu_ref.cpp — the kernels' integer headers compiled for the host; explicit backend, not a
-    fallback and not the oracle), the same synchronous TD(0) step on `batch` lanes, 1 thread and all host threads."""
+    fallback and not the oracle), the same synchronous TD(0) step on `batch` lanes, 1 thread and all the host threads this process may use (at most 16: the CPU share of a 1-GPU box)."""
     lines = {'what': f'lib2048_cpu.so (csrc/cpu_ref.cpp), full TD(0) step, n={n}, {batch} lanes, sum rule, ~{seconds:.0f} s each', 'unit': 'board-steps/s'}
-    allt = max(1, min(os.cpu_count() or 1, 64))
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    allt = max(1, min(usable, 16))       # (a 1-GPU box gives this process a share of 16 cores whatever the host's core count says)
     for label, threads, lanes in (('one_thread', 1, batch), ('all_threads', allt, batch * 16)):
         os.environ['G2048_CPU_THREADS'] = str(threads)
         eng = pkg.Engine(lanes, n=n, seed=2048, backend='cpu')
