@@ -21,7 +21,12 @@
  *     library orders their device work by the order of the CALLS (each table-using call first makes its stream wait
  *     for the latest table-using call of any sibling), so the caller must issue calls on contexts that share a table
  *     from one thread at a time, and two such contexts never step concurrently.
- *   - there is NO CPU implementation behind this ABI: g2048_create fails with G2048_ERR_NODEV without a GPU.
+ *   - TWO LIBRARIES export this ABI: lib2048_hip.so (2048_amd/csrc/g2048.hip — the product; g2048_create fails with
+ *     G2048_ERR_NODEV without a GPU and never routes anywhere else) and lib2048_cpu.so (2048_amd/csrc/cpu_ref.cpp — the same
+ *     entry points in scalar C++ from the kernels' integer headers: SURVEY.md 8b's `cpu_ref`).  Which one a process loads is
+ *     the caller's explicit choice; neither falls back to the other.  Differences of the CPU library: "device" pointers are
+ *     host pointers, device 0 is the host, g2048_comm_* / g2048_allreduce_* return G2048_ERR_COMM, the debug entry points of
+ *     GPU-only machinery (lane order, owner plan) report nothing.
  */
 #ifndef G2048_H
 #define G2048_H
