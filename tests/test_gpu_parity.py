@@ -331,12 +331,13 @@ def test_td_large_batch_vs_oracle_through_replans():
     eng.close()
 
 
-@pytest.mark.parametrize('n,B', [(4, 4096), (5, 5000), (6, 1237)])
+@pytest.mark.parametrize('n,B', [(2, 3000), (3, 3001), (4, 4096), (5, 5000), (6, 1237)])
 def test_td_hot_set_path_vs_oracle(n, B, monkeypatch):
     """k_td_play's LDS hot set (the first 2 048 entries of every four-cell table in memory order — small tiles — read from
     an LDS copy; the other lanes' gathers issued under their exec mask through an asm load; on by default from 2^18 lanes)
     forced on at a small batch: mid-game boards mix hot and cold tuples, random boards of tiles 0..13 are almost all cold; every
-    step is checked against the float64 oracle as everywhere else."""
+    step is checked against the float64 oracle as everywhere else.  n = 2, 3: their LDS forms (the whole table; the entries
+    whose three cells are all below 8, the others through the same asm loads), which otherwise start at 2^14 / 2^17 lanes."""
     monkeypatch.setenv('G2048_PLAY_HOT_MIN', '1')
     monkeypatch.setenv('G2048_PLAY_HOT', '2')                # (2: for n = 6 too, where it is off by default)
     eng = Engine(B, n=n, seed=900 + n)
@@ -442,14 +443,16 @@ def test_lane_sort_same_games_at_scale():
     assert a[4]['moves'] == b[4]['moves'] == B * steps and abs(a[4]['episodes'] - b[4]['episodes']) <= 64
 
 
-@pytest.mark.parametrize('n', [5, 6])
+@pytest.mark.parametrize('n', [2, 3, 5, 6])
 def test_td_config4_full_size_owner_path(n):
     """BASELINE config 4 at its full size — 2^20 lanes, n = 5, the LDS-owner update the bench times — and the per-GPU
     workload of config 5 (n = 6: the binned f_6 update on top of it).  Per step:
     a slice of lanes is replayed by the float64 oracle (their choices depend only on the table before the step: boards,
     scores, RNG, carried state and labels bit for bit), every live lane moves once, and the table's total change equals
-    8 F sum(dw) with the records' dw rebuilt from the lanes' exported state (r_learning.py:240,248)."""
-    B, F = 1 << 20, {5: 21, 6: 33}[n]
+    8 F sum(dw) with the records' dw rebuilt from the lanes' exported state (r_learning.py:240,248).
+    n = 2, 3 (round 3): the same at full size through their own kernels — the table (n = 2) / its small-tile part (n = 3) in LDS
+    for the gathers (k_td_play_lds2 / _lds3) and the orbit-reduced owner update (24 / 52 adds per record instead of 192 / 416)."""
+    B, F = 1 << 20, {2: 24, 3: 52, 5: 21, 6: 33}[n]
     alpha = formulas.exact_alpha(n)
     eng = Engine(B, n=n, seed=4)
     eng.set_auto_reset(False)
