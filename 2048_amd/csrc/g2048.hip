@@ -3177,10 +3177,13 @@ int replan(g2048_ctx* c) {
 // a kernel that takes more than 64 KB of dynamic LDS has to be told so once (per process: the attribute belongs to the function)
 template <class K>
 void allow_dynamic_lds(K kernel, uint32_t bytes) {
-    static bool done = false;
-    if (bytes > 65536u && !done) {
+    static bool done[64] = {};             // per device: the attribute is set on the current device's copy of the function
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    dev = dev >= 0 && dev < 64 ? dev : 0;
+    if (bytes > 65536u && !done[dev]) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-        done = true;
+        done[dev] = true;
     }
 }
 
