@@ -201,7 +201,7 @@ def load_traffic(n, B):
 
 
 def build_roofline(eng, n, B, ms_step, ms_play, ms_owner, ms_tail, ms_apply, st, copy_gbps):
-    """The measurement block (prompt section 4).  Top level: the contract's fields for the dominant
+    """The measurement block of the JSON line.  Top level: the contract's fields for the dominant
     kernel — `achieved` = the reference algorithm's bytes for that kernel over its measured duration, against the
     8 TB/s HBM peak, `traffic` = its PMC-measured HBM bytes.  Below it, per kernel, the bound each one actually hits, every
     fraction <= 1 by construction (bytes or operations the kernel really moves / performs over its own time):
