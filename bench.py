@@ -228,7 +228,11 @@ def build_roofline(eng, n, B, ms_step, ms_play, ms_owner, ms_tail, ms_apply, st,
            'traffic': pm('k_td_play', 'hbm_bytes'), 'traffic_source': pmc_note or 'profiles/traffic.json (tools/pmc_traffic.py), same lib2048_hip.so',
            'algorithmic_bytes_per_launch': by_play * B, 'ms_per_launch': ms_play, 'longest_kernel': dominant, 'ms_kernels': kernels_ms,
            'note': 'achieved = reference-algorithm bytes (SURVEY.md 8d: 72 + 4 F 4 + 20 per board-step) / kernel time: the contract\'s yardstick.  '
-                   'The table gathers it counts are served by L2 / LDS, not HBM: the bounds the kernels really hit are under `kernels`.'}
+                   'The table gathers it counts are served by L2 / LDS, not HBM: the bounds the kernels really hit are under `kernels`.  '
+                   'ms_per_launch is the HIP-event average of 20 steady-state steps of the TIMED path (sum rule, conditioned boards).  A rocprofv3 '
+                   'per-kernel average over this whole command also contains the young boards of the conditioning phase (faster) and, unless '
+                   '--no-mean-line / --trained-steps 0 are given, the mean-rule leg and the trained-agent leg (slower: `trained_agent.ms_kernels`); '
+                   'profiles/r03_bench_driver_timed_path_kernel_stats.csv is the trace of the timed path alone.'}
     kern = {}
     # ---- k_td_play
     k = {'ms': ms_play, 'share_of_step': ms_play / ms_step, 'limits': []}

@@ -30,6 +30,10 @@ pmc() {     # CONFIG PASSNAME "COUNTERS" n batch bench-flags...
 
 FAST="--steps 10 --warmup 10 --repeats 1 --no-cpu-baseline --no-mean-line --trained-steps 0"
 trace bench_driver --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline
+# the same command without its two extra legs (mean rule on the same boards; 3 000 more training steps + a timing on the trained
+# agent's boards): rocprofv3's per-kernel AVERAGE over the full command mixes three input distributions, this one is the
+# sum-rule path the metric is quoted on (conditioning + warm-up + timed regions + the 20 event-timed steps)
+trace bench_driver_timed_path --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-mean-line --trained-steps 0
 trace bench_default --no-cpu-baseline
 trace bench_n6 --n-tuple 6 --steps 50 --warmup 20 --no-cpu-baseline --no-mean-line --trained-steps 0
 trace config2_env --workload env --steps 200
