@@ -601,40 +601,10 @@ __device__ __forceinline__ Choice choose_hot(const float* __restrict__ w, const 
         _Pragma("unroll") for (int f = 17; f < F; ++f) acc_ += XC[f - 17];                 \
         V = acc_;                                                                           \
     }
-#ifdef G2048_EXP_LDS_FIRST       // (experiment: all four directions' LDS reads, ONE wait, then all masked loads — 68 offsets stay live in between)
-#define G2048_HOT_PREP(M, OFF, CH, XC, MSV)                                                 \
-    uint32_t OFF[17], MSV[F > 17 ? F - 17 : 1];                                             \
-    const bool CH = (M).changed;                                                            \
-    {                                                                                       \
-        uint32_t s_[F], ms_[F];                                                             \
-        feature_slots<N>(pack_board((M).after), s_);                                        \
-        memory_slots<N>(pack_board((M).after), ms_);                                        \
-        _Pragma("unroll") for (int f = 0; f < 17; ++f) OFF[f] = bit_transpose16(s_[f] & 0xFFFFu); \
-        _Pragma("unroll") for (int f = 17; f < F; ++f) MSV[f - 17] = ms_[f];                \
-    }
-#define G2048_HOT_LDS2(f, reg) asm volatile("ds_read_b32 " reg ", %0" ::"v"(hot_base + (((uint32_t)(f) * HOT_PER_FEATURE + (T_[f] & (HOT_PER_FEATURE - 1u))) << 2)));
-    G2048_HOT_PREP(mv.m0, t0, ch0, xc0, q0)
-    G2048_HOT_PREP(mv.m1, t1, ch1, xc1, q1)
-    G2048_HOT_PREP(mv.m2, t2, ch2, xc2, q2)
-    G2048_HOT_PREP(mv.m3, t3, ch3, xc3, q3)
-    { const uint32_t* T_ = t0; G2048_HOT_REGS0(G2048_HOT_LDS2) }
-    { const uint32_t* T_ = t1; G2048_HOT_REGS1(G2048_HOT_LDS2) }
-    { const uint32_t* T_ = t2; G2048_HOT_REGS2(G2048_HOT_LDS2) }
-    { const uint32_t* T_ = t3; G2048_HOT_REGS3(G2048_HOT_LDS2) }
-    asm volatile("s_waitcnt lgkmcnt(0)");
-    float xc0[F > 17 ? F - 17 : 1], xc1[F > 17 ? F - 17 : 1], xc2[F > 17 ? F - 17 : 1], xc3[F > 17 ? F - 17 : 1];
-    { const uint32_t* T_ = t0; const bool changed_ = ch0; G2048_HOT_REGS0(G2048_HOT_GLB) _Pragma("unroll") for (int f = 17; f < F; ++f) xc0[f - 17] = ld_w(w, changed_ ? q0[f - 17] : 0u); }
-    { const uint32_t* T_ = t1; const bool changed_ = ch1; G2048_HOT_REGS1(G2048_HOT_GLB) _Pragma("unroll") for (int f = 17; f < F; ++f) xc1[f - 17] = ld_w(w, changed_ ? q1[f - 17] : 0u); }
-    { const uint32_t* T_ = t2; const bool changed_ = ch2; G2048_HOT_REGS2(G2048_HOT_GLB) _Pragma("unroll") for (int f = 17; f < F; ++f) xc2[f - 17] = ld_w(w, changed_ ? q2[f - 17] : 0u); }
-    { const uint32_t* T_ = t3; const bool changed_ = ch3; G2048_HOT_REGS3(G2048_HOT_GLB) _Pragma("unroll") for (int f = 17; f < F; ++f) xc3[f - 17] = ld_w(w, changed_ ? q3[f - 17] : 0u); }
-#undef G2048_HOT_PREP
-#undef G2048_HOT_LDS2
-#else
     G2048_HOT_DIR(mv.m0, G2048_HOT_REGS0, xc0)
     G2048_HOT_DIR(mv.m1, G2048_HOT_REGS1, xc1)
     G2048_HOT_DIR(mv.m2, G2048_HOT_REGS2, xc2)
     G2048_HOT_DIR(mv.m3, G2048_HOT_REGS3, xc3)
-#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     G2048_HOT_SUM(G2048_HOT_REGS0, xc0, v0)
     G2048_HOT_SUM(G2048_HOT_REGS1, xc1, v1)
