@@ -307,20 +307,77 @@ G2048_HD void feature_slots<6>(const Packed& p, uint32_t out[33]) {
     hex_slots(p, out + 21);
 }
 
-// feature_slots at their places in memory: what the kernels that read or write the table use (n = 2, 3: index order)
-template <int N>
-G2048_HD void memory_slots(const Packed& p, uint32_t* out) {
-    feature_slots<N>(p, out);
-    if (N >= 4) {
-        for (int f = 0; f < (N == 4 ? 17 : 21); ++f) out[f] = table_place(out[f]);
+// ---- feature_slots at their places in memory: what the kernels that read or write the table use (n = 2, 3: index order)
+// The four- and five-cell features are computed IN the transposed domain instead of transposing 21 indices one by one:
+// only the eight line indices are transposed (two per 32-bit word: no shift of the network crosses a half), and in a
+// transposed line — [bit 3 of its four cells | bit 2 | bit 1 | bit 0], cell j at bit 3 - j of each group — the bits of two
+// neighbouring cells are neighbours, so a square or a cross is two masked shifts of its lines.  (~95 VALU instructions per
+// board instead of ~240; tests/test_hostcheck_logic.py holds it to table_place(feature_slots).)
+G2048_HD uint32_t bit_transpose16x2(uint32_t x) {     // both 16-bit halves transposed
+    uint32_t t = (x ^ (x >> 3)) & 0x0A0A0A0Au;
+    x ^= t ^ (t << 3);
+    t = (x ^ (x >> 6)) & 0x00CC00CCu;
+    x ^= t ^ (t << 6);
+    return x;
+}
+struct PlacedLines {
+    uint32_t R[4], C[4];        // table_place of the packed rows / columns
+};
+G2048_HD PlacedLines place_lines(const Packed& p) {
+    PlacedLines t;
+#pragma unroll
+    for (int i = 0; i < 4; i += 2) {
+        const uint32_t r = bit_transpose16x2(p.R[i] | p.R[i + 1] << 16), c = bit_transpose16x2(p.C[i] | p.C[i + 1] << 16);
+        t.R[i] = r & 0xFFFFu;
+        t.R[i + 1] = r >> 16;
+        t.C[i] = c & 0xFFFFu;
+        t.C[i + 1] = c >> 16;
+    }
+    return t;
+}
+// table_place(quad_slots(p)[f]) - f * 65536: the place inside the feature's own table
+G2048_HD void quad_places(const PlacedLines& t, uint32_t out[17]) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) out[c] = t.C[c];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[4 + r] = t.R[r];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {       // square (r, c) = cells r, r + 1 of columns c and c + 1: bits 3 - r, 2 - r of every group
+        uint32_t m[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) m[c] = (t.C[c] >> (2 - r)) & 0x3333u;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) out[8 + 3 * r + c] = m[c] << 2 | m[c + 1];
     }
 }
-template <>
-G2048_HD void memory_slots<6>(const Packed& p, uint32_t* out) {
-    quad_slots(p, out);
-    cross_slots(p, out + 17);
-    for (int f = 0; f < 21; ++f) out[f] = table_place(out[f]);
-    hex_slots_placed(p, out + 21);
+// table_place(cross_slots(p)[j]) - CROSS_BASE - j * 1048576 (centre << 16 | up, left, down, right transposed)
+G2048_HD void cross_places(const Packed& p, const PlacedLines& t, uint32_t out[4]) {
+#pragma unroll
+    for (int r = 1; r < 3; ++r)
+#pragma unroll
+        for (int c = 1; c < 3; ++c) {
+            const uint32_t ud = (t.C[c] >> (2 - r)) & 0x5555u;      // up at bit 2, down at bit 0 of every group
+            const uint32_t lr = (t.R[r] >> (2 - c)) & 0x5555u;      // left at bit 2, right at bit 0
+            out[2 * (r - 1) + (c - 1)] = (G2048_CELL(p, r, c) << 16) | ud << 1 | lr;
+        }
+}
+
+template <int N>
+G2048_HD void memory_slots(const Packed& p, uint32_t* out) {
+    if constexpr (N < 4) {
+        feature_slots<N>(p, out);
+    } else {
+        const PlacedLines t = place_lines(p);
+        quad_places(t, out);
+#pragma unroll
+        for (int f = 0; f < 17; ++f) out[f] += (uint32_t)f * 65536u;
+        if constexpr (N >= 5) {
+            cross_places(p, t, out + 17);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) out[17 + j] += CROSS_BASE + (uint32_t)j * 1048576u;
+        }
+        if constexpr (N == 6) hex_slots_placed(p, out + 21);
+    }
 }
 
 // first slot of feature i (host-side layout queries)

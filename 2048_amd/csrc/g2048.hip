@@ -577,16 +577,20 @@ __device__ __forceinline__ Choice choose_hot(const float* __restrict__ w, const 
     int first_valid = -1;
     // phase A + B of one direction: T[f] = the gather's place in its table (memory order), hot iff T[f] < HOT_PER_FEATURE
 #define G2048_HOT_LDS(f, reg) asm volatile("ds_read_b32 " reg ", %0" ::"v"(hot_base + (((uint32_t)(f) * HOT_PER_FEATURE + (T_[f] & (HOT_PER_FEATURE - 1u))) << 2)));
+#ifdef G2048_EXP_NOCOLD          // (experiment: what the cold four-cell gathers cost — every lane keeps its LDS word)
+#define G2048_HOT_COLD(f) false
+#else
+#define G2048_HOT_COLD(f) (T_[f] >= HOT_PER_FEATURE)
+#endif
 #define G2048_HOT_GLB(f, reg) \
-    if (changed_ && T_[f] >= HOT_PER_FEATURE) asm volatile("global_load_dword " reg ", %0, %1" G2048_COLD_POLICY ::"v"(((uint32_t)(f) * 65536u + T_[f]) << 2), "s"(w));
+    if (changed_ && G2048_HOT_COLD(f)) asm volatile("global_load_dword " reg ", %0, %1" G2048_COLD_POLICY ::"v"(((uint32_t)(f) * 65536u + T_[f]) << 2), "s"(w));
 #define G2048_HOT_DIR(M, REGS, XC)                                                          \
     float XC[F > 17 ? F - 17 : 1];                                                          \
     {                                                                                       \
-        uint32_t s_[F], ms_[F], T_[17];                                                     \
+        uint32_t ms_[F], T_[17];                                                            \
         const bool changed_ = (M).changed;                                                  \
-        feature_slots<N>(pack_board((M).after), s_);                                        \
-        memory_slots<N>(pack_board((M).after), ms_);        /* (used for the features behind the four-cell ones) */ \
-        _Pragma("unroll") for (int f = 0; f < 17; ++f) T_[f] = bit_transpose16(s_[f] & 0xFFFFu); \
+        memory_slots<N>(pack_board((M).after), ms_);                                        \
+        _Pragma("unroll") for (int f = 0; f < 17; ++f) T_[f] = ms_[f] - (uint32_t)f * 65536u;      /* the place inside the feature's table */ \
         REGS(G2048_HOT_LDS)                                                                 \
         asm volatile("s_waitcnt lgkmcnt(0)");       /* the LDS words are in before a global load may land on top of them */ \
         REGS(G2048_HOT_GLB)                                                                 \
