@@ -320,18 +320,58 @@ G2048_HD uint32_t bit_transpose16x2(uint32_t x) {     // both 16-bit halves tran
     x ^= t ^ (t << 6);
     return x;
 }
+// the packed lines of a board two to a word: RR[k] = R[2k] | R[2k + 1] << 16, CC likewise
+struct PackedPairs {
+    uint32_t RR[2], CC[2];
+};
+// pack16 of two byte-words at once: (w << 4 | w >> 8) has b0 << 4 | b1 in byte 0 and b2 << 4 | b3 in byte 2, and one byte
+// permute puts the four bytes of two lines in place (5 instructions for two lines instead of 14)
+G2048_HD uint32_t pack16x2(uint32_t w0, uint32_t w1) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t u0 = (w0 << 4) | (w0 >> 8), u1 = (w1 << 4) | (w1 >> 8);
+    return __builtin_amdgcn_perm(u1, u0, 0x04060002u);      // bytes, low to high: u0.2, u0.0, u1.2, u1.0
+#else
+    return pack16(w0) | pack16(w1) << 16;
+#endif
+}
+G2048_HD PackedPairs pack_pairs(const uint32_t rows[4], const uint32_t cols[4]) {
+    PackedPairs q;
+    q.RR[0] = pack16x2(rows[0], rows[1]);
+    q.RR[1] = pack16x2(rows[2], rows[3]);
+    q.CC[0] = pack16x2(cols[0], cols[1]);
+    q.CC[1] = pack16x2(cols[2], cols[3]);
+    return q;
+}
+G2048_HD PackedPairs pack_pairs(const Board& b) {
+    uint32_t cols[4];
+    transpose(b.r, cols);
+    return pack_pairs(b.r, cols);
+}
+G2048_HD PackedPairs pair_up(const Packed& p) {
+    return PackedPairs{{p.R[0] | p.R[1] << 16, p.R[2] | p.R[3] << 16}, {p.C[0] | p.C[1] << 16, p.C[2] | p.C[3] << 16}};
+}
+G2048_HD Packed unpair(const PackedPairs& q) {
+    Packed p;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        p.R[i] = (i & 1) ? q.RR[i >> 1] >> 16 : q.RR[i >> 1] & 0xFFFFu;
+        p.C[i] = (i & 1) ? q.CC[i >> 1] >> 16 : q.CC[i >> 1] & 0xFFFFu;
+    }
+    return p;
+}
+
 struct PlacedLines {
     uint32_t R[4], C[4];        // table_place of the packed rows / columns
 };
-G2048_HD PlacedLines place_lines(const Packed& p) {
+G2048_HD PlacedLines place_lines(const PackedPairs& q) {
     PlacedLines t;
 #pragma unroll
-    for (int i = 0; i < 4; i += 2) {
-        const uint32_t r = bit_transpose16x2(p.R[i] | p.R[i + 1] << 16), c = bit_transpose16x2(p.C[i] | p.C[i + 1] << 16);
-        t.R[i] = r & 0xFFFFu;
-        t.R[i + 1] = r >> 16;
-        t.C[i] = c & 0xFFFFu;
-        t.C[i + 1] = c >> 16;
+    for (int k = 0; k < 2; ++k) {
+        const uint32_t r = bit_transpose16x2(q.RR[k]), c = bit_transpose16x2(q.CC[k]);
+        t.R[2 * k] = r & 0xFFFFu;
+        t.R[2 * k + 1] = r >> 16;
+        t.C[2 * k] = c & 0xFFFFu;
+        t.C[2 * k + 1] = c >> 16;
     }
     return t;
 }
@@ -351,33 +391,41 @@ G2048_HD void quad_places(const PlacedLines& t, uint32_t out[17]) {
     }
 }
 // table_place(cross_slots(p)[j]) - CROSS_BASE - j * 1048576 (centre << 16 | up, left, down, right transposed)
-G2048_HD void cross_places(const Packed& p, const PlacedLines& t, uint32_t out[4]) {
+G2048_HD void cross_places(const PackedPairs& q, const PlacedLines& t, uint32_t out[4]) {
 #pragma unroll
     for (int r = 1; r < 3; ++r)
 #pragma unroll
         for (int c = 1; c < 3; ++c) {
             const uint32_t ud = (t.C[c] >> (2 - r)) & 0x5555u;      // up at bit 2, down at bit 0 of every group
             const uint32_t lr = (t.R[r] >> (2 - c)) & 0x5555u;      // left at bit 2, right at bit 0
-            out[2 * (r - 1) + (c - 1)] = (G2048_CELL(p, r, c) << 16) | ud << 1 | lr;
+            const uint32_t centre = (q.RR[r >> 1] >> (16 * (r & 1) + 12 - 4 * c)) & 0xFu;
+            out[2 * (r - 1) + (c - 1)] = centre << 16 | ud << 1 | lr;
         }
 }
 
 template <int N>
-G2048_HD void memory_slots(const Packed& p, uint32_t* out) {
+G2048_HD void memory_slots(const PackedPairs& q, uint32_t* out) {
     if constexpr (N < 4) {
-        feature_slots<N>(p, out);
+        feature_slots<N>(unpair(q), out);
     } else {
-        const PlacedLines t = place_lines(p);
+        const PlacedLines t = place_lines(q);
         quad_places(t, out);
 #pragma unroll
         for (int f = 0; f < 17; ++f) out[f] += (uint32_t)f * 65536u;
         if constexpr (N >= 5) {
-            cross_places(p, t, out + 17);
+            cross_places(q, t, out + 17);
 #pragma unroll
             for (int j = 0; j < 4; ++j) out[17 + j] += CROSS_BASE + (uint32_t)j * 1048576u;
         }
-        if constexpr (N == 6) hex_slots_placed(p, out + 21);
+        if constexpr (N == 6) hex_slots_placed(unpair(q), out + 21);
     }
+}
+template <int N>
+G2048_HD void memory_slots(const Packed& p, uint32_t* out) {
+    if constexpr (N < 4)
+        feature_slots<N>(p, out);
+    else
+        memory_slots<N>(pair_up(p), out);
 }
 
 // first slot of feature i (host-side layout queries)

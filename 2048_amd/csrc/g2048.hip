@@ -358,7 +358,7 @@ template <int N>
 __device__ __forceinline__ float value_of(const float* __restrict__ w, const Board& b) {
     constexpr int F = Shape<N>::F;
     uint32_t s[F];
-    memory_slots<N>(pack_board(b), s);
+    memory_slots<N>(pack_pairs(b), s);
     float x[F];
 #pragma unroll
     for (int f = 0; f < F; ++f) x[f] = ld_w(w, s[f]);
@@ -403,10 +403,10 @@ __device__ __forceinline__ Choice choose(const float* __restrict__ w, const Move
     int first_valid = -1;
     if constexpr (F <= G2048_BATCH4_MAXF) {
         uint32_t s0[F], s1[F], s2[F], s3[F];
-        memory_slots<N>(pack_board(mv.m0.after), s0);
-        memory_slots<N>(pack_board(mv.m1.after), s1);
-        memory_slots<N>(pack_board(mv.m2.after), s2);
-        memory_slots<N>(pack_board(mv.m3.after), s3);
+        memory_slots<N>(pack_pairs(mv.m0.after), s0);
+        memory_slots<N>(pack_pairs(mv.m1.after), s1);
+        memory_slots<N>(pack_pairs(mv.m2.after), s2);
+        memory_slots<N>(pack_pairs(mv.m3.after), s3);
         float x0[F], x1[F], x2[F], x3[F];
 #pragma unroll
         for (int f = 0; f < F; ++f) {
@@ -442,8 +442,8 @@ __device__ __forceinline__ Choice choose(const float* __restrict__ w, const Move
 #define G2048_TRY_PAIR(DA, MA, DB, MB)                                               \
     {                                                                                \
         uint32_t sa[F], sb[F];                                                       \
-        memory_slots<N>(pack_board((MA).after), sa);                                \
-        memory_slots<N>(pack_board((MB).after), sb);                                \
+        memory_slots<N>(pack_pairs((MA).after), sa);                                \
+        memory_slots<N>(pack_pairs((MB).after), sb);                                \
         float xa[F], xb[F];                                                          \
         _Pragma("unroll") for (int f = 0; f < F; ++f) {                              \
             xa[f] = ld_w_f<N>(w, (MA).changed ? sa[f] : 0u, f);                      \
@@ -589,7 +589,7 @@ __device__ __forceinline__ Choice choose_hot(const float* __restrict__ w, const 
     {                                                                                       \
         uint32_t ms_[F], T_[17];                                                            \
         const bool changed_ = (M).changed;                                                  \
-        memory_slots<N>(pack_board((M).after), ms_);                                        \
+        memory_slots<N>(pack_pairs((M).after), ms_);                                        \
         _Pragma("unroll") for (int f = 0; f < 17; ++f) T_[f] = ms_[f] - (uint32_t)f * 65536u;      /* the place inside the feature's table */ \
         REGS(G2048_HOT_LDS)                                                                 \
         asm volatile("s_waitcnt lgkmcnt(0)");       /* the LDS words are in before a global load may land on top of them */ \
