@@ -2136,8 +2136,26 @@ __global__ __launch_bounds__(WG) void k_hex_apply(float* w, float* dacc, float* 
 constexpr uint32_t SORT_TILE = 5;               // default threshold (G2048_SORT_TILE): key bit set for tiles above 2^5
 constexpr uint32_t SORT_KEYS = 65536, SORT_TPB = 1024, SORT_PER_THREAD = 4, SORT_LANES_PER_WG = SORT_TPB * SORT_PER_THREAD;
 
+// (round 3, late) WHERE the big tiles sit and WHAT they are: value >> 1 of every tile above thr — what such a tile contributes to
+// the address of a table line (a 64-byte line of a table in table_place order holds the 16 entries that differ in bit 0 of
+// the four cells) — folded into 16 bits by a multiplicative hash.  Lanes with the same big tiles
+// in the same places share a bucket; the order of the buckets means nothing.
+constexpr uint32_t SORT_BY_VALUE = 16u;         // flag in the `thr` argument of the sort kernels
+__device__ __forceinline__ uint32_t sort_key_values(const Board& b, uint32_t thr) {
+    uint32_t h = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const uint32_t v = (b.r[r] >> (8 * c)) & 0xFFu;
+            h = h * 0x9E3779B1u + (v > thr ? (v >> 1) & 7u : 0u);
+        }
+    return (h >> 16) ^ (h & 0xFFFFu);
+}
+
 // one bit per cell, row 0 in the top nibble: tile > thr (tiles are < 128, so the carry into bit 7 of each byte lane is the test)
 __device__ __forceinline__ uint32_t sort_key(const Board& b, uint32_t thr) {
+    if (thr & SORT_BY_VALUE) return sort_key_values(b, thr & 15u);
     const uint32_t bias = (0x7Fu - thr) * 0x01010101u;
     uint32_t key = 0;
 #pragma unroll
@@ -2435,9 +2453,10 @@ struct g2048_ctx {
         double plan_mixed = 6.0;        // XCD-resident plan: chunks that deserve fewer workgroups than this are scanned flat (0: none)
         unsigned play_wgs = 0;
         uint32_t play_dynamic = 2;      // full rounds of k_td_play's lane blocks left to the counter (besides the last, partial one)
-        uint32_t sort_every = 16;       // default of g2048_set_lane_sort for new contexts (G2048_SORT_EVERY); 0 = never
+        uint32_t sort_every = 8;        // default of g2048_set_lane_sort for new contexts (G2048_SORT_EVERY); 0 = never
         uint32_t sort_min_batch = 1u << 17;     // smaller batches keep their lane order
         uint32_t sort_tile = SORT_TILE; // key bit of a cell: tile above 2^this (G2048_SORT_TILE)
+        uint32_t sort_values = 1;       // the key also tells the big tiles' values apart (hashed; G2048_SORT_VALUES=0: positions only, round 2's key)
         uint32_t sort_lag = 2;          // steps between the boards a sort looks at and the step that applies it (G2048_SORT_LAG; 0 = sort in line)
         int hex_bins = 1;               // n = 6: f_6 orbits through k_hex_* (0: k_td_update_tail's scattered atomics)
         int delta_accum = 0;            // multi-GPU epoch delta: 0 = W - W0 when it is asked for, 1 = every add of a step mirrored in an accumulator
@@ -2538,6 +2557,7 @@ void read_knobs(g2048_ctx* c) {
     if (const char* e = getenv("G2048_SORT_EVERY")) k.sort_every = (uint32_t)atoi(e);
     if (const char* e = getenv("G2048_SORT_MIN")) k.sort_min_batch = (uint32_t)atoi(e);
     if (const char* e = getenv("G2048_SORT_LAG")) k.sort_lag = (uint32_t)atoi(e);
+    if (const char* e = getenv("G2048_SORT_VALUES")) k.sort_values = (uint32_t)atoi(e);
     if (const char* e = getenv("G2048_SORT_TILE")) k.sort_tile = (uint32_t)atoi(e) < 15u ? (uint32_t)atoi(e) : 15u;
     if (const char* e = getenv("G2048_DELTA_ACCUM")) k.delta_accum = atoi(e);
     if (const char* e = getenv("G2048_PLAY_HOT_MIN")) k.play_hot_min = (uint32_t)atoi(e);
@@ -2614,7 +2634,7 @@ int lane_sort_prepare(g2048_ctx* c) {
 int lane_sort_permutation(g2048_ctx* c, bool side) {
     if (int rc = lane_sort_prepare(c)) return rc;
     if (c->sort_issued) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_sort_done, 0));       // (an abandoned sort may still be reading its buffers)
-    k_sort_count<<<(c->B + SORT_LANES_PER_WG - 1) / SORT_LANES_PER_WG, SORT_TPB, 0, c->stream>>>(c->boards, c->B, c->knob.sort_tile, c->sort_cnt, c->sort_key16,
+    k_sort_count<<<(c->B + SORT_LANES_PER_WG - 1) / SORT_LANES_PER_WG, SORT_TPB, 0, c->stream>>>(c->boards, c->B, c->knob.sort_tile | (c->knob.sort_values ? SORT_BY_VALUE : 0u), c->sort_cnt, c->sort_key16,
                                                                                            c->sort_off);
     hipStream_t st = c->stream;
     if (side) {

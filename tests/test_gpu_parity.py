@@ -381,18 +381,29 @@ def test_lane_sort_is_invisible(n, lag, monkeypatch):
     eng.close()
 
 
+@pytest.mark.parametrize('by_value', [1, 0])
 @pytest.mark.parametrize('B', [1, 777, 4096, 4097, (1 << 18) + 13])
-def test_lane_order_is_a_sorted_permutation(B):
+def test_lane_order_is_a_sorted_permutation(B, by_value, monkeypatch):
     """The hand-written lane re-order (k_sort_count / k_sort_scan / k_sort_scatter): its output is a permutation of the
-    positions, non-decreasing in the key, and the key is one bit per cell — tile above 32 — row 0 in the top nibble.  Ragged
-    sizes around the 4 096-lane tile of a workgroup; run twice (the bucket counters must be back at zero)."""
+    positions, non-decreasing in the key.  The key (default): value >> 1 of every tile above 32, by cell, folded into 16 bits
+    by a multiplicative hash — lanes with the same big tiles in the same places share a bucket; G2048_SORT_VALUES=0: one bit per
+    cell — tile above 32 — row 0 in the top nibble (round 2's key).  Ragged sizes around the 4 096-lane tile of a workgroup;
+    run twice (the bucket counters must be back at zero)."""
+    monkeypatch.setenv('G2048_SORT_VALUES', str(by_value))
     eng = Engine(B, n=4, seed=31 + B)
     eng.step_random(150)                                     # mid-game boards: many distinct patterns
     boards = eng.get_boards().reshape(B, 16)
     want = np.zeros(B, np.uint32)
-    for cell in range(16):
-        r, c = divmod(cell, 4)
-        want |= (boards[:, cell] > 5).astype(np.uint32) << (4 * (3 - r) + c)
+    if by_value:
+        h = np.zeros(B, np.uint64)
+        for cell in range(16):                               # row-major, as the kernel walks the board
+            v = boards[:, cell].astype(np.uint64)
+            h = (h * np.uint64(0x9E3779B1) + np.where(v > 5, (v >> np.uint64(1)) & np.uint64(7), 0).astype(np.uint64)) & np.uint64(0xFFFFFFFF)
+        want = ((h >> np.uint64(16)) ^ (h & np.uint64(0xFFFF))).astype(np.uint32)
+    else:
+        for cell in range(16):
+            r, c = divmod(cell, 4)
+            want |= (boards[:, cell] > 5).astype(np.uint32) << (4 * (3 - r) + c)
     for _ in range(2):
         perm, keys = eng.debug_lane_order()
         assert np.array_equal(keys, want.astype(np.uint16))
