@@ -44,15 +44,15 @@ def report(tag, eng, lanes=65536):
     f = e.features().astype(np.int64).reshape(lanes, 4, F)
     e.close()
     valid = ((changed[:, None] >> np.arange(4)[None, :]) & 1).astype(bool)
-    q = f[:, :, :17] - (np.arange(17) * 65536)[None, None, :]
-    x = f[:, :, 17:] - (17 * 65536 + np.arange(4) * 1048576)[None, None, :]
+    q = f[:, :, :17]                 # (Engine.features: every feature's index inside its own table)
+    x = f[:, :, 17:]
     qt = transpose16(q)
     xt, xc = transpose16(x & 0xFFFF), x >> 16
     print(f'{tag}: {valid.sum()} valid directions of {lanes} lanes')
     qv, xtv, xcv = qt[valid], xt[valid], xc[valid]
     for lim in (256, 512, 1024, 2048, 4096):
         print(f'    four-cell  t < {lim:5d}: {lim * 17 * 4 // 1024:4d} KB  {np.mean(qv < lim):6.1%} of the four-cell gathers')
-    for cl, tl in ((4, 256), (4, 1024), (8, 256), (8, 512), (8, 1024), (8, 4096), (16, 256), (16, 1024)):
+    for cl, tl in ((4, 256), (4, 1024), (6, 256), (8, 256), (8, 512), (8, 1024), (8, 4096), (16, 256), (16, 1024)):
         m = (xcv < cl) & (xtv < tl)
         print(f'    cross centre < {cl:2d}, t < {tl:5d}: {cl * tl * 16 // 1024:4d} KB  {m.mean():6.1%} of the five-cell gathers')
     lq = lines_per_wave(qt, valid)

@@ -60,7 +60,7 @@ def report(eng, lanes=1 << 19):
     f = e.features().astype(np.int64).reshape(lanes, 4, F)
     e.close()
     valid = ((changed[:, None] >> np.arange(4)[None, :]) & 1).astype(bool)
-    q = f[:, :, :17] - (np.arange(17) * 65536)[None, None, :]
+    q = f[:, :, :17]                # (Engine.features: every feature's index inside its own table)
     cold = transpose16(q) >= HOT
     for name, line in groupings(q).items():
         tot = 0

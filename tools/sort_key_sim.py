@@ -84,8 +84,8 @@ def report(tag, eng, lanes=1 << 20):
         f = e.features().astype(np.int64).reshape(lanes, 4, F)
         e.close()
         valid = ((changed[:, None] >> np.arange(4)[None, :]) & 1).astype(bool)
-        q = transpose16(f[:, :, :17] - (np.arange(17) * 65536)[None, None, :])
-        x = f[:, :, 17:] - (17 * 65536 + np.arange(4) * 1048576)[None, None, :]
+        q = transpose16(f[:, :, :17])           # (Engine.features: every feature's index inside its own table)
+        x = f[:, :, 17:]
         xp = ((x >> 16) << 16) | transpose16(x & 0xFFFF)
         tq = tx = 0
         for d in range(4):
