@@ -28,6 +28,7 @@
 #include <algorithm>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/g2048.h"
@@ -1734,15 +1735,25 @@ __global__ __launch_bounds__(OWN_WG) void k_td_update_owner(float* dst, float* c
 // The planner's statistics (hit counters + workgroup clocks of the owner kernel that just ran, 17 KB) go to their pinned
 // host mirror from inside the apply kernel — the first blocks store them over PCIe — instead of through a copy command:
 // a blit kernel on a side stream took 11-17 us beside every k_td_play (rocprofv3, round 2).
+// The host learns that they have arrived from a sequence number the same block stores behind them (late round 3): an event
+// recorded between this kernel and the next step's k_td_play is a marker packet in the queue, and the command processor spent
+// 6 us on it every step before it dispatched k_td_play (rocprofv3 trace: the only gap in the step's chain).
 struct StatMirror {
     const uint32_t* src;    // device: statbuf
     uint32_t* dst;          // pinned host memory (device-visible); null: no mirror this step
     uint32_t words;
+    uint32_t seq;           // stored at dst[words] once the statistics are in host memory
+    uint32_t* done;         // device counter of the mirroring blocks
 };
 __device__ __forceinline__ void mirror_stats(const StatMirror& m) {
-    if (!m.dst) return;
+    const uint32_t nblk = (m.words + blockDim.x - 1) / blockDim.x;     // the first blocks store one word per thread
+    if (!m.dst || blockIdx.x >= nblk) return;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < m.words) m.dst[i] = __hip_atomic_load(&m.src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (written by the previous kernel: bypass a stale L1 line)
+    __threadfence_system();
+    __syncthreads();
+    // the block that finishes last announces the set (a counter that is never reset: every mirroring launch adds nblk to it)
+    if (threadIdx.x == 0 && atomicAdd(m.done, 1u) % nblk == nblk - 1u) __hip_atomic_store(&m.dst[m.words], m.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // table_i[perm_i(k)] += v for every member i of the orbit; `dacc` (may be null) mirrors the add (g2048_delta_begin)
@@ -2379,7 +2390,9 @@ struct g2048_ctx {
     int cur = 0;                        // which half of `prev` holds the current `state`
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_plan = nullptr;
-    bool plan_pending = false;          // stats_readback recorded its event, replan has not looked at the statistics yet
+    bool plan_pending = false;          // stats_readback asked for the statistics, replan has not looked at them yet
+    uint32_t mirror_seq = 0;            // sequence number of the last apply kernel launched with a mirror
+    uint32_t mirror_want = 0;           // the one replan waits for
     uint4* boards = nullptr;
     int32_t* scores = nullptr;
     ulonglong2* rng = nullptr;
@@ -2456,6 +2469,7 @@ struct g2048_ctx {
         uint32_t sort_every = 8;        // default of g2048_set_lane_sort for new contexts (G2048_SORT_EVERY); 0 = never
         uint32_t sort_min_batch = 1u << 17;     // smaller batches keep their lane order
         uint32_t sort_tile = SORT_TILE; // key bit of a cell: tile above 2^this (G2048_SORT_TILE)
+        uint32_t plan_poll = 1;         // the planner's statistics are announced by the apply kernel itself (0: an event behind it; G2048_PLAN_POLL)
         uint32_t sort_values = 1;       // the key also tells the big tiles' values apart (hashed; G2048_SORT_VALUES=0: positions only, round 2's key)
         uint32_t sort_lag = 2;          // steps between the boards a sort looks at and the step that applies it (G2048_SORT_LAG; 0 = sort in line)
         int hex_bins = 1;               // n = 6: f_6 orbits through k_hex_* (0: k_td_update_tail's scattered atomics)
@@ -2557,6 +2571,7 @@ void read_knobs(g2048_ctx* c) {
     if (const char* e = getenv("G2048_SORT_EVERY")) k.sort_every = (uint32_t)atoi(e);
     if (const char* e = getenv("G2048_SORT_MIN")) k.sort_min_batch = (uint32_t)atoi(e);
     if (const char* e = getenv("G2048_SORT_LAG")) k.sort_lag = (uint32_t)atoi(e);
+    if (const char* e = getenv("G2048_PLAN_POLL")) k.plan_poll = (uint32_t)atoi(e);
     if (const char* e = getenv("G2048_SORT_VALUES")) k.sort_values = (uint32_t)atoi(e);
     if (const char* e = getenv("G2048_SORT_TILE")) k.sort_tile = (uint32_t)atoi(e) < 15u ? (uint32_t)atoi(e) : 15u;
     if (const char* e = getenv("G2048_DELTA_ACCUM")) k.delta_accum = atoi(e);
@@ -2898,11 +2913,12 @@ int build_slices(g2048_ctx* c) {
             }
         }
         if (int rc = dalloc(c, &c->slices, MAX_SLICES)) return rc;
-        if (int rc = dalloc(c, &c->statbuf, STAT_BYTES)) return rc;
-        HIP_TRY(c, hipMemset(c->statbuf, 0, STAT_BYTES));
+        if (int rc = dalloc(c, &c->statbuf, STAT_BYTES + 64)) return rc;       // (+ mirror_stats' block counter)
+        HIP_TRY(c, hipMemset(c->statbuf, 0, STAT_BYTES + 64));
         c->hits = reinterpret_cast<uint32_t*>(c->statbuf);
         c->wg_clock = reinterpret_cast<uint64_t*>(c->statbuf + HITS_CAP * 4);
-        HIP_TRY(c, hipHostMalloc((void**)&c->h_stat, STAT_BYTES, hipHostMallocMapped));
+        HIP_TRY(c, hipHostMalloc((void**)&c->h_stat, STAT_BYTES + 64, hipHostMallocMapped));        // (+ the mirror's sequence number)
+        memset(c->h_stat, 0, STAT_BYTES + 64);
         HIP_TRY(c, hipHostGetDevicePointer(&c->h_stat_dev, c->h_stat, 0));
         HIP_TRY(c, hipHostMalloc((void**)&c->h_slices, MAX_SLICES * sizeof(Slice), hipHostMallocDefault));
     }
@@ -3097,9 +3113,26 @@ int build_slices(g2048_ctx* c) {
 // event marks that kernel's end.
 int stats_readback(g2048_ctx* c) {
     if (c->n < 4 || c->n_chunks == 0 || c->steps_since_read == 0) return G2048_OK;
-    HIP_TRY(c, hipEventRecord(c->ev_plan, c->stream));      // behind the previous step's apply kernel, which stored the statistics
+    if (c->knob.plan_poll && c->mirror_seq)
+        c->mirror_want = c->mirror_seq;                         // the previous step's apply kernel announces them itself (mirror_stats)
+    else
+        HIP_TRY(c, hipEventRecord(c->ev_plan, c->stream));      // behind the previous step's apply kernel, which stored the statistics
     c->plan_pending = true;
     return G2048_OK;
+}
+
+// wait until the apply kernel with sequence number `want` has stored its statistics (it is queued in front of the k_td_play
+// just launched: a fraction of a step away).  Bounded: a lost store must not hang the host.
+bool mirror_arrived(const g2048_ctx* c, uint32_t want) {
+    const volatile uint32_t* seq = reinterpret_cast<const volatile uint32_t*>(c->h_stat + STAT_BYTES);
+    for (uint64_t spin = 0; spin < (1ull << 26); ++spin) {
+        if ((int32_t)(*seq - want) >= 0) {
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);
+            return true;
+        }
+        if ((spin & 1023u) == 1023u) std::this_thread::yield();
+    }
+    return false;
 }
 
 // Second half (AFTER k_td_play is launched, before the update's launch): wait for that copy — the GPU is busy with
@@ -3111,7 +3144,13 @@ int stats_readback(g2048_ctx* c) {
 int replan(g2048_ctx* c) {
     if (!c->plan_pending) return G2048_OK;
     c->plan_pending = false;
-    HIP_TRY(c, hipEventSynchronize(c->ev_plan));
+    if (c->mirror_want) {
+        const uint32_t want = c->mirror_want;
+        c->mirror_want = 0;
+        if (!mirror_arrived(c, want)) HIP_TRY(c, hipStreamSynchronize(c->stream));
+    } else {
+        HIP_TRY(c, hipEventSynchronize(c->ev_plan));
+    }
     const uint32_t* h = reinterpret_cast<const uint32_t*>(c->h_stat);
     uint64_t fresh_total = 0;
     for (size_t k = 0; k < c->n_chunks; ++k) fresh_total += h[k] - c->hits_seen[k];          // cumulative counters, modulo 2^32
@@ -3344,7 +3383,8 @@ int launch_td_step(g2048_ctx* c, float alpha, hipEvent_t ev = nullptr, hipEvent_
         }
         if (ev_tail) (void)hipEventRecord(ev_tail, c->stream);
         const StatMirror sm{reinterpret_cast<const uint32_t*>(c->statbuf), c->n >= 4 ? reinterpret_cast<uint32_t*>(c->h_stat_dev) : nullptr,
-                            (uint32_t)(STAT_BYTES / 4)};
+                            (uint32_t)(STAT_BYTES / 4), c->n >= 4 ? ++c->mirror_seq : 0u,
+                            reinterpret_cast<uint32_t*>(c->statbuf + STAT_BYTES)};
         OrbitTable ot = c->orbits;
         if (hex_binned) ot.total = c->owned_total;      // the f_6 orbit tables are applied chunk by chunk (k_hex_apply)
         if (c->update_rule == 1)
