@@ -1745,9 +1745,12 @@ struct StatMirror {
     uint32_t seq;           // stored at dst[words] once the statistics are in host memory
     uint32_t* done;         // device counter of the mirroring blocks
 };
+// The first mirror_blocks() blocks of an apply launch do nothing else (the system-scope fence waits for the stores' trip over
+// PCIe, ~2 us: inside a block that also has table work it lengthened the kernel by that much); the others see their index shifted.
+__host__ __device__ __forceinline__ uint32_t mirror_blocks(const StatMirror& m) { return m.dst ? (m.words + WG - 1) / WG : 0u; }
 __device__ __forceinline__ void mirror_stats(const StatMirror& m) {
-    const uint32_t nblk = (m.words + blockDim.x - 1) / blockDim.x;     // the first blocks store one word per thread
-    if (!m.dst || blockIdx.x >= nblk) return;
+    const uint32_t nblk = mirror_blocks(m);     // one word per thread
+    if (blockIdx.x >= nblk) return;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < m.words) m.dst[i] = __hip_atomic_load(&m.src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (written by the previous kernel: bypass a stale L1 line)
     __threadfence_system();
@@ -1776,7 +1779,8 @@ __device__ __forceinline__ void add_to_members(float* w, float* dacc, const Orbi
 __global__ __launch_bounds__(WG) void k_apply_orbits(float* w, float* dacc, float* D, const float* cur, float* oth, uint32_t owned, OrbitTable t,
                                                       StatMirror sm) {
     mirror_stats(sm);
-    const uint32_t K = blockIdx.x * WG + threadIdx.x;
+    if (blockIdx.x < mirror_blocks(sm)) return;
+    const uint32_t K = (blockIdx.x - mirror_blocks(sm)) * WG + threadIdx.x;
     if (K >= t.total) return;
     if (K < owned) oth[K] = 0.0f;
     uint32_t o = 0;
@@ -1817,7 +1821,8 @@ __global__ __launch_bounds__(WG) void k_apply_orbits(float* w, float* dacc, floa
 __global__ __launch_bounds__(WG) void k_apply_orbits_mean(float* w, float* dacc, float* S, float* C, const float* scur, const float* ccur, float* soth,
                                                           float* coth, uint32_t owned, OrbitTable t, StatMirror sm) {
     mirror_stats(sm);
-    const uint32_t K = blockIdx.x * WG + threadIdx.x;
+    if (blockIdx.x < mirror_blocks(sm)) return;
+    const uint32_t K = (blockIdx.x - mirror_blocks(sm)) * WG + threadIdx.x;
     if (K >= t.total) return;
     if (K < owned) {
         soth[K] = 0.0f;
@@ -3388,9 +3393,9 @@ int launch_td_step(g2048_ctx* c, float alpha, hipEvent_t ev = nullptr, hipEvent_
         OrbitTable ot = c->orbits;
         if (hex_binned) ot.total = c->owned_total;      // the f_6 orbit tables are applied chunk by chunk (k_hex_apply)
         if (c->update_rule == 1)
-            k_apply_orbits_mean<<<grid_for(ot.total), WG, 0, c->stream>>>(c->w, dacc, c->D, c->Dcnt, Dcur, Ccur, Doth, Coth, c->owned_total, ot, sm);
+            k_apply_orbits_mean<<<grid_for(ot.total) + mirror_blocks(sm), WG, 0, c->stream>>>(c->w, dacc, c->D, c->Dcnt, Dcur, Ccur, Doth, Coth, c->owned_total, ot, sm);
         else
-            k_apply_orbits<<<grid_for(ot.total), WG, 0, c->stream>>>(c->w, dacc, c->D, Dcur, Doth, c->owned_total, ot, sm);
+            k_apply_orbits<<<grid_for(ot.total) + mirror_blocks(sm), WG, 0, c->stream>>>(c->w, dacc, c->D, Dcur, Doth, c->owned_total, ot, sm);
         if (hex_binned) {
             const uint32_t hb = c->orbits.o[6].base;
             k_hex_apply<<<grid_for(HEX_SLOTS), WG, 0, c->stream>>>(c->w, dacc, c->D + hb, c->update_rule == 1 ? c->Dcnt + hb : nullptr, c->hex, c->orbits.o[6], c->orbits.o[7]);
