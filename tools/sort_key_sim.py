@@ -28,12 +28,12 @@ def distinct_per_wave(lines, active):
     return d.sum()
 
 
-def mix(k):
-    k = (k * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF if False else k
+def mix16(k):
+    """a 16-bit hash of a 64-bit key (a stand-in for the kernel's multiplicative hash: what matters is that equal keys meet)"""
     k = np.asarray(k, np.uint64)
     k = (k ^ (k >> np.uint64(31))) * np.uint64(0x9E3779B97F4A7C15)
     k = (k ^ (k >> np.uint64(29))) * np.uint64(0xBF58476D1CE4E5B9)
-    return (k ^ (k >> np.uint64(32))) & np.uint64(0xFFFF)
+    return ((k ^ (k >> np.uint64(32))) & np.uint64(0xFFFF)).astype(np.int64)
 
 
 def lex(h):
@@ -46,31 +46,25 @@ def lex(h):
 def orders(boards):
     """name -> permutation of the lanes"""
     b = boards.reshape(len(boards), 16).astype(np.int64)
-    rng = np.random.RandomState(1)
-    out = {}
-    out['lane id (no sort)'] = np.arange(len(b))
-    big = b > 5
-    pos = (big << np.arange(15, -1, -1)).sum(axis=1)
-    shuffled = rng.permutation(len(b))                      # the counting sort leaves the order inside a bucket arbitrary
-    first = shuffled[np.argsort(pos[shuffled], kind='stable')]
-    out['shipped: bit per cell, tile > 32'] = first
-    full = lex(np.where(big, b >> 1, 0))
-    out['v >> 1 of tiles > 32, lexicographic, global sort'] = np.argsort(full, kind='stable')
-    for tile in (4096, 16384):
-        o = first.copy()
-        for lo in range(0, len(o), tile):
-            seg = o[lo:lo + tile]
-            o[lo:lo + tile] = seg[np.lexsort((full[seg], pos[seg]))]
-        out[f'shipped, then every {tile}-lane tile of that order sorted by (positions, v >> 1 lexicographic)'] = o
-    # the same with the lexicographic key's top 15 bits (cells 0..4) as the first pass
-    top = full >> 33
-    first2 = shuffled[np.argsort(top[shuffled], kind='stable')]
-    o = first2.copy()
-    for lo in range(0, len(o), 4096):
-        seg = o[lo:lo + 4096]
-        o[lo:lo + 4096] = seg[np.argsort(full[seg], kind='stable')]
-    out['top 15 bits of the lexicographic key, then 4096-lane tiles sorted by all of it'] = o
-    exact = lex(np.where(big, b - 5, 0) >> 0) if False else None
+    shuffled = np.random.RandomState(1).permutation(len(b))         # the counting sort leaves the order inside a bucket arbitrary
+    by = lambda key: shuffled[np.argsort(key[shuffled], kind='stable')]
+    out = {'lane id (no sort)': np.arange(len(b))}
+    for thr in (5, 4, 6):
+        big = b > thr
+        pos = (big << np.arange(15, -1, -1)).sum(axis=1)
+        full = lex(np.where(big, b >> 1, 0))
+        if thr == 5:
+            out['one bit per cell, tile > 32 (round 2)'] = by(pos)
+            out['value >> 1 of tiles > 32, lexicographic, global sort'] = np.argsort(full, kind='stable')
+            out['the same string hashed to 16 bits (shipped)'] = by(mix16(full))
+            o = by(pos).copy()
+            for lo in range(0, len(o), 4096):
+                seg = o[lo:lo + 4096]
+                o[lo:lo + 4096] = seg[np.lexsort((full[seg], pos[seg]))]
+            out['round-2 key, then every 4096-lane tile sorted by the string'] = o
+            out['value (not >> 1) of tiles > 32, hashed'] = by(mix16(lex(np.where(big, b, 0) & 7) * 16 + (lex(np.where(big, b >> 3, 0)) & 0xFFFF)))
+        else:
+            out[f'value >> 1 of tiles > {1 << thr}, hashed'] = by(mix16(full))
     return out
 
 
