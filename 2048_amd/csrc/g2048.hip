@@ -1349,9 +1349,9 @@ struct Slice {
     uint64_t fb_mask;
     uint32_t cshift;        // log2 of the slots per chunk of this orbit table (OWN_SLOTS, or OWN_SLOTS / 2 for the fixed-point orbits)
     uint32_t fixed;         // 1: this workgroup sums in 64-bit fixed point (own_fixed, or every variant under the one-pass mean rule)
-    uint32_t xcd;           // 1: XCD-resident plan — part = x * (nparts / 8) + j scans its share (`blocks`) of XCD x's record blocks
+    uint32_t xcd;           // 1: XCD-resident plan — part = x * (nparts / 8) + j scans every (nparts / 8)-th, from the j-th on, of XCD x's record blocks
     uint32_t recs_bound;    // no more main records than this are scanned by this workgroup (sizes the fixed-point fields)
-    const unsigned long long* blocks;   // XCD-resident plan: OWN_PERIOD bits (device memory) — bit t = the record blocks b with b % OWN_PERIOD == t are this part's
+    uint64_t blocks[4];     // XCD-resident plan: bit t = the record blocks b with b % 256 == t belong to this workgroup's XCD
 };
 
 // Symmetry orbits (n >= 4).  QAgent.update adds dw at f_i(g.x) for all 8 images g (r_learning.py:207-214).  Features
@@ -1421,11 +1421,6 @@ G2048_HD uint32_t permute_hex_placed(uint32_t k, uint32_t perm) {
 #define G2048_OWN_U 4       // records per thread in flight in the owner kernel's scan (n >= 4)
 #endif
 constexpr int OWN_WG = 1024;
-#ifndef G2048_OWN_BLOCK
-#define G2048_OWN_BLOCK 4096
-#endif
-constexpr uint32_t OWN_BLOCK = G2048_OWN_BLOCK;    // records per block of the owner kernel's scan (n >= 4): what the parts of a chunk are dealt
-constexpr uint32_t OWN_PERIOD = 1024;              // XCD-resident plan: the pattern that deals the blocks repeats after this many
 constexpr uint32_t OWN_SLOTS = 32768;      // 128 KiB of the CU's 160 KiB LDS
 template <int FC> struct OwnUnroll { static constexpr int U = FC == 1 ? 4 : 1; };   // records in flight per thread (loads issued together)
 
@@ -1584,49 +1579,44 @@ __device__ __forceinline__ void own_run(float* acc, const Slice& s, const TdRecs
         // a part takes every nparts-th block of records, not one contiguous range: the lanes may be ordered by board
         // pattern (LaneSort), and neighbouring records then hit the same few slots
         // (XCD-resident plan: the blocks b = x (mod 8) belong to XCD x for EVERY chunk, so that one L2 serves all their scans)
-        constexpr uint32_t BLK = OWN_BLOCK, NONE = 0xFFFFFFFFu, SUB = OWN_BLOCK / OWN_WG, NB = U / SUB;     // NB blocks per turn of the loop
-        static_assert(OWN_BLOCK % OWN_WG == 0 && U % SUB == 0 && NB >= 1, "a block is a whole number of the workgroup's loads, a turn a whole number of blocks");
+        constexpr uint32_t BLK = OWN_WG * U;
         const uint32_t nblk = (B + BLK - 1) / BLK, end = B;
-        // (XCD-resident plan: which blocks are this part's is a bit pattern of OWN_PERIOD blocks made by the planner, s.blocks.  All
-        // the parts on XCD x, whatever their chunk, share XCD x's blocks among them — with every XCD at the same speed the blocks
-        // b = x (mod 8); the XCDs of an MI355X do not run this kernel at the same speed — the two halves of the chip differ by
-        // 10-18 %, which half is the slow one differs from box to box — and the planner moves blocks between them by the
-        // workgroup clocks it reads back: xcd_balance)
-        uint32_t flat_next = s.part, word = 0;                // word: which 64 blocks `left` describes
-        unsigned long long left = s.xcd ? s.blocks[0] : 0ull;
-        // the next block of this part, NONE when there is none (all scalar: s is wave-uniform, the pattern comes through scalar loads)
-        auto next_block = [&]() -> uint32_t {
-            if (!s.xcd) {
-                const uint32_t b = flat_next;
-                if (b >= nblk) return NONE;
-                flat_next += s.nparts;
-                return b;
-            }
-            while (word * 64u < nblk) {
-                if (left) {
-                    const uint32_t b = word * 64u + (uint32_t)__builtin_ctzll(left);
-                    left &= left - 1ull;
-                    if (b < nblk) return b;
-                    break;                      // (bits are visited in increasing order: nothing below nblk is left)
-                }
-                ++word;
-                left = s.blocks[word & (OWN_PERIOD / 64u - 1u)];
-            }
-            word = NONE / 64u;
-            left = 0;
-            return NONE;
-        };
+        // (which blocks are XCD x's is a 256-block pattern, s.blocks: bit t set = the blocks b = t (mod 256).  With every XCD at the
+        // same speed that is b = x (mod 8); the XCDs of an MI355X do not run this kernel at the same speed — the two halves of
+        // the chip differ by 10-18 %, which half is the slow one differs from box to box — and the planner moves blocks between
+        // them by the workgroup clocks it reads back: xcd_balance)
+        const uint32_t per_xcd = s.xcd ? s.nparts >> 3 : 1u, mine = s.xcd ? s.part % per_xcd : 0u;
+        uint32_t blk = s.part, word = 0, seen = 0;           // word: which 64 blocks `left` describes
+        unsigned long long left = s.blocks[0];
         for (;;) {
-            uint32_t bl[NB];
-#pragma unroll
-            for (uint32_t k = 0; k < NB; ++k) bl[k] = next_block();
-            if (bl[0] == NONE) break;
+            if (s.xcd) {            // the next block of this XCD whose turn it is for this part (all scalar: s is wave-uniform)
+                bool found = false;
+                while (word * 64u < nblk && !found) {
+                    while (left && !found) {
+                        const uint32_t t = (uint32_t)__builtin_ctzll(left);
+                        left &= left - 1ull;
+                        if (seen++ % per_xcd == mine) {
+                            blk = word * 64u + t;
+                            found = true;
+                        }
+                    }
+                    if (!found) {
+                        ++word;
+                        const uint32_t w4 = word & 3u;          // (no dynamic index into the kernel argument copy)
+                        left = w4 == 0u ? s.blocks[0] : w4 == 1u ? s.blocks[1] : w4 == 2u ? s.blocks[2] : s.blocks[3];
+                    }
+                }
+                if (!found || blk >= nblk) break;      // (the pattern's bits are visited in increasing order: nothing below nblk is left)
+            } else if (blk >= nblk) {
+                break;
+            }
+            const uint32_t base0 = blk * BLK;
             uint32_t idx[U][NI];
             float dw[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const uint32_t b = bl[(uint32_t)u / SUB], r = b * BLK + ((uint32_t)u % SUB) * OWN_WG + threadIdx.x;
-                const bool ok = b != NONE && r < end;
+                const uint32_t r = base0 + threadIdx.x + (uint32_t)u * OWN_WG;
+                const bool ok = r < end;
                 const uint32_t rr = ok ? r : end - 1;
                 if constexpr (V < 4) {
                     const uint2 t = oi.q[(size_t)V * B + rr];
@@ -1644,6 +1634,7 @@ __device__ __forceinline__ void own_run(float* acc, const Slice& s, const TdRecs
 #pragma unroll
             for (int u = 0; u < U; ++u)
                 own_accum_idx<NI, FB, FIXED>(idx[u], dw[u], dw[u] != 0.0f, acc, s, lo_rel, nhit_wave, D, Dc, fb_hits, (double)scale, cbits);
+            if (!s.xcd) blk += s.nparts;
         }
     } else {   // main records: this part's share of the lanes, OWN_UNROLL records per thread in flight; the loop bounds are
         // wave-uniform
@@ -2497,9 +2488,6 @@ struct g2048_ctx {
     // XCD balance (late round 3): how many of every 64 record blocks each XCD scans under the XCD-resident plan (sum 64; the block
     // patterns are cut at a quarter of that: 256-block period), and the
     // smoothed mean duration of each XCD's workgroups in the launches read back since the shares last changed
-    unsigned long long* slice_blocks = nullptr;     // device: [MAX_SLICES][OWN_PERIOD / 64] block patterns of the XCD-resident slices
-    unsigned long long* h_blocks = nullptr;         // pinned staging of the same
-    std::vector<uint64_t> plan_blocks;              // the patterns of c->plan
     double xcd_share[8] = {8, 8, 8, 8, 8, 8, 8, 8};
     double xcd_dur[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t xcd_dur_n = 0;
@@ -2975,8 +2963,6 @@ int build_slices(g2048_ctx* c) {
         memset(c->h_stat, 0, STAT_BYTES + 64);
         HIP_TRY(c, hipHostGetDevicePointer(&c->h_stat_dev, c->h_stat, 0));
         HIP_TRY(c, hipHostMalloc((void**)&c->h_slices, MAX_SLICES * sizeof(Slice), hipHostMallocDefault));
-        if (int rc = dalloc(c, &c->slice_blocks, (size_t)MAX_SLICES * (OWN_PERIOD / 64u))) return rc;
-        HIP_TRY(c, hipHostMalloc((void**)&c->h_blocks, (size_t)MAX_SLICES * (OWN_PERIOD / 8u), hipHostMallocDefault));
     }
     const std::vector<ChunkInfo> chunks = table_chunks(c);
     const size_t nc = chunks.size();
@@ -3055,12 +3041,11 @@ int build_slices(g2048_ctx* c) {
         }
     }
     std::vector<Slice> v;
-    std::vector<uint64_t> blocks((size_t)MAX_SLICES * (OWN_PERIOD / 64u), 0ull);      // the XCD-resident slices' block patterns, one row per slice
     std::vector<uint32_t> parts(nc, 0);
     auto slice_of = [&](size_t k, uint32_t p, uint32_t np) {
         return Slice{chunks[k].variant, chunks[k].tlo, chunks[k].size, chunks[k].dlo, p, np, (uint32_t)k,
                      chunks[k].orb_tlo, chunks[k].orb_dlo, chunks[k].chunk0, duty[k], chunks[k].size >= OWN_SLOTS ? 15u : 14u,
-                     chunk_fixed(c, (int)chunks[k].variant) ? 1u : 0u, 0u, (c->B + np - 1) / np + 4096u, nullptr};      // (flat: blocks dealt round-robin)
+                     chunk_fixed(c, (int)chunks[k].variant) ? 1u : 0u, 0u, (c->B + np - 1) / np + 4096u, {0ull, 0ull, 0ull, 0ull}};      // (blocks of <= 4096 records, dealt round-robin)
     };
     // 0: flat plan; 1 (default where it applies): XCD-resident scan.  (Cutting the chunks into pieces packed onto the 32
     // workgroups of an XCD, a workgroup running its pieces one after the other, was tried: 0.296 -> 0.311 ms per step.)
@@ -3119,19 +3104,20 @@ int build_slices(g2048_ctx* c) {
         std::stable_sort(per_xcd.begin(), per_xcd.end(), [&](const std::pair<size_t, uint32_t>& a, const std::pair<size_t, uint32_t>& b) {
             return cost[a.first] / parts[a.first] > cost[b.first] / parts[b.first];
         });
-        // which XCD scans which record block: of every OWN_PERIOD blocks XCD x gets its share (xcd_share, largest remainders first) —
-        // its own b = x (mod 8) first, then what the others leave.  A chunk's parts on XCD x then take that XCD's blocks in turn.
-        uint8_t owner[OWN_PERIOD];
+        // the XCDs' block patterns: of every 256 record blocks XCD x gets round(4 x xcd_share[x]) (largest remainders first,
+        // sum 256) — its own b = x (mod 8) first, then what the others leave
+        uint64_t pattern[XCDS][4] = {};
         {
+            constexpr uint32_t PERIOD = 256;
             uint32_t quota[XCDS], given = 0;
             double rem[XCDS];
             for (uint32_t x = 0; x < XCDS; ++x) {
-                const double want = c->xcd_share[x] * (OWN_PERIOD / 64.0);
+                const double want = c->xcd_share[x] * (PERIOD / 64.0);
                 quota[x] = (uint32_t)want;
                 rem[x] = want - quota[x];
                 given += quota[x];
             }
-            while (given < OWN_PERIOD) {
+            while (given < PERIOD) {
                 uint32_t best = 0;
                 for (uint32_t x = 1; x < XCDS; ++x)
                     if (rem[x] > rem[best]) best = x;
@@ -3139,38 +3125,37 @@ int build_slices(g2048_ctx* c) {
                 rem[best] = -1.0;
                 ++given;
             }
-            for (uint32_t t = 0; t < OWN_PERIOD; ++t) {
+            uint32_t spare[PERIOD], nspare = 0;
+            for (uint32_t t = 0; t < PERIOD; ++t) {
                 if (quota[t % XCDS]) {
-                    owner[t] = (uint8_t)(t % XCDS);
+                    pattern[t % XCDS][t >> 6] |= 1ull << (t & 63u);
                     --quota[t % XCDS];
                 } else {
-                    owner[t] = 0xFF;
+                    spare[nspare++] = t;
                 }
             }
-            for (uint32_t t = 0; t < OWN_PERIOD; ++t)
-                if (owner[t] == 0xFF) {
-                    uint32_t best = 0;
-                    for (uint32_t x = 1; x < XCDS; ++x)
-                        if (quota[x] > quota[best]) best = x;
-                    owner[t] = (uint8_t)best;
-                    --quota[best];
-                }
+            for (uint32_t i = 0; i < nspare; ++i) {
+                uint32_t best = 0;
+                for (uint32_t x = 1; x < XCDS; ++x)
+                    if (quota[x] > quota[best]) best = x;
+                pattern[best][spare[i] >> 6] |= 1ull << (spare[i] & 63u);
+                --quota[best];
+            }
         }
-        const uint32_t nblk = (c->B + OWN_BLOCK - 1u) / OWN_BLOCK;
-        constexpr uint32_t WORDS = OWN_PERIOD / 64u;
+        const uint32_t nblk = (c->B + 4095u) / 4096u;           // (OWN_WG x G2048_OWN_U records per block: own_run)
+        static_assert(OWN_WG * G2048_OWN_U == 4096, "the planner counts record blocks of 4 096");
         for (const auto& kj : per_xcd)
             for (uint32_t x = 0; x < XCDS; ++x)
             {
                 const uint32_t np = parts[kj.first];
                 Slice sl = slice_of(kj.first, x * np + kj.second, XCDS * np);
                 sl.xcd = 1u;
-                sl.blocks = c->slice_blocks + v.size() * WORDS;         // (filled below: this slice's row of plan_blocks)
-                uint64_t* row = blocks.data() + v.size() * WORDS;
-                uint32_t seen = 0, mine = 0;
-                for (uint32_t t = 0; t < OWN_PERIOD; ++t)
-                    if (owner[t] == x && seen++ % np == kj.second) row[t >> 6] |= 1ull << (t & 63u);
-                for (uint32_t b = 0; b < nblk; ++b) mine += (uint32_t)((row[(b % OWN_PERIOD) >> 6] >> (b & 63u)) & 1ull);
-                sl.recs_bound = mine * OWN_BLOCK + 4096u;
+                for (int q = 0; q < 4; ++q) sl.blocks[q] = pattern[x][q];
+                uint32_t mine = 0, seen = 0;                    // the blocks own_run will hand this part
+                for (uint32_t b = 0; b < nblk; ++b)
+                    if ((pattern[x][(b & 255u) >> 6] >> (b & 63u)) & 1ull)
+                        if (seen++ % np == kj.second) ++mine;
+                sl.recs_bound = mine * 4096u + 4096u;
                 v.push_back(sl);
             }
         for (size_t k = 0; k < nc; ++k)                                     // the flat ones behind the groups of 8
@@ -3198,7 +3183,6 @@ int build_slices(g2048_ctx* c) {
     if (v.size() > MAX_SLICES) return fail(c, G2048_ERR_STATE, "LDS-owner plan too large");
     c->n_slices = (uint32_t)v.size();
     c->plan = v;
-    c->plan_blocks.swap(blocks);
     if (c->knob.debug_plan) {
         fprintf(stderr, "[g2048 plan] %zu workgroups over %zu chunks; (chunk:load/parts)", v.size(), nc);
         for (size_t k = 0; k < nc; ++k) fprintf(stderr, " %zu:%.3f/%u", k, c->load[k] / (8.0 * B), parts[k]);
@@ -3208,11 +3192,6 @@ int build_slices(g2048_ctx* c) {
     // next replan's readback has synchronised the stream
     memcpy(c->h_slices, v.data(), v.size() * sizeof(Slice));
     HIP_TRY(c, hipMemcpyAsync(c->slices, c->h_slices, v.size() * sizeof(Slice), hipMemcpyHostToDevice, c->stream));
-    if (!v.empty() && v[0].xcd) {           // (the XCD-resident slices come first: their rows of block patterns)
-        const size_t bytes = v.size() * (OWN_PERIOD / 8u);
-        memcpy(c->h_blocks, c->plan_blocks.data(), bytes);
-        HIP_TRY(c, hipMemcpyAsync(c->slice_blocks, c->h_blocks, bytes, hipMemcpyHostToDevice, c->stream));
-    }
     c->steps_since_plan = 0;
     c->makespan_ref = 0;
     return G2048_OK;
@@ -3626,7 +3605,7 @@ int g2048_destroy(g2048_ctx* c) {
         if (c->parent->last_user == c) c->parent->last_user = nullptr;
     }
     void* bufs[] = {c->log.moves, c->log.start, c->log.final, c->log.meta, c->boards, c->scores, c->rng, c->prev[0], c->prev[1], c->oidx[0], c->oidx[1], c->label, c->flags, c->dw1, c->qstate,
-                    c->qdw,    c->qcount, c->last_move, c->w,      c->w0,  c->delta,   c->stats,   c->scratch, c->slices, c->slice_blocks, c->statbuf, c->D, c->Dcnt, c->D2, c->Dcnt2, c->pack, c->lane_id,
+                    c->qdw,    c->qcount, c->last_move, c->w,      c->w0,  c->delta,   c->stats,   c->scratch, c->slices, c->statbuf, c->D, c->Dcnt, c->D2, c->Dcnt2, c->pack, c->lane_id,
                     c->alt.boards, c->alt.scores, c->alt.rng, c->alt.label, c->alt.flags, c->alt.lane_id, c->alt.last_move,
                     c->sort_key16, c->sort_off, c->sort_perm, c->sort_cnt, c->sort_start,
                     c->hex.count, c->hex.base, c->hex.cursor, c->hex.pairs, c->hex.work, c->hex.nwork};
@@ -3634,7 +3613,6 @@ int g2048_destroy(g2048_ctx* c) {
         if (p && (p != (void*)c->w || c->owns_table)) (void)hipFree(p);
     if (c->h_stat) (void)hipHostFree(c->h_stat);
     if (c->h_slices) (void)hipHostFree(c->h_slices);
-    if (c->h_blocks) (void)hipHostFree(c->h_blocks);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev_plan) (void)hipEventDestroy(c->ev_plan);
     if (c->ev_table) (void)hipEventDestroy(c->ev_table);
