@@ -1349,9 +1349,7 @@ struct Slice {
     uint64_t fb_mask;
     uint32_t cshift;        // log2 of the slots per chunk of this orbit table (OWN_SLOTS, or OWN_SLOTS / 2 for the fixed-point orbits)
     uint32_t fixed;         // 1: this workgroup sums in 64-bit fixed point (own_fixed, or every variant under the one-pass mean rule)
-    uint32_t xcd;           // 1: XCD-resident plan — part = x * (nparts / 8) + j scans every (nparts / 8)-th, from the j-th on, of XCD x's record blocks
-    uint32_t recs_bound;    // no more main records than this are scanned by this workgroup (sizes the fixed-point fields)
-    uint64_t blocks[4];     // XCD-resident plan: bit t = the record blocks b with b % 256 == t belong to this workgroup's XCD
+    uint32_t xcd;           // 1: XCD-resident plan — part = x * (nparts / 8) + j scans the record blocks b = x + 8 * (j + (nparts / 8) * t)
 };
 
 // Symmetry orbits (n >= 4).  QAgent.update adds dw at f_i(g.x) for all 8 images g (r_learning.py:207-214).  Features
@@ -1581,35 +1579,9 @@ __device__ __forceinline__ void own_run(float* acc, const Slice& s, const TdRecs
         // (XCD-resident plan: the blocks b = x (mod 8) belong to XCD x for EVERY chunk, so that one L2 serves all their scans)
         constexpr uint32_t BLK = OWN_WG * U;
         const uint32_t nblk = (B + BLK - 1) / BLK, end = B;
-        // (which blocks are XCD x's is a 256-block pattern, s.blocks: bit t set = the blocks b = t (mod 256).  With every XCD at the
-        // same speed that is b = x (mod 8); the XCDs of an MI355X do not run this kernel at the same speed — the two halves of
-        // the chip differ by 10-18 %, which half is the slow one differs from box to box — and the planner moves blocks between
-        // them by the workgroup clocks it reads back: xcd_balance)
-        const uint32_t per_xcd = s.xcd ? s.nparts >> 3 : 1u, mine = s.xcd ? s.part % per_xcd : 0u;
-        uint32_t blk = s.part, word = 0, seen = 0;           // word: which 64 blocks `left` describes
-        unsigned long long left = s.blocks[0];
-        for (;;) {
-            if (s.xcd) {            // the next block of this XCD whose turn it is for this part (all scalar: s is wave-uniform)
-                bool found = false;
-                while (word * 64u < nblk && !found) {
-                    while (left && !found) {
-                        const uint32_t t = (uint32_t)__builtin_ctzll(left);
-                        left &= left - 1ull;
-                        if (seen++ % per_xcd == mine) {
-                            blk = word * 64u + t;
-                            found = true;
-                        }
-                    }
-                    if (!found) {
-                        ++word;
-                        const uint32_t w4 = word & 3u;          // (no dynamic index into the kernel argument copy)
-                        left = w4 == 0u ? s.blocks[0] : w4 == 1u ? s.blocks[1] : w4 == 2u ? s.blocks[2] : s.blocks[3];
-                    }
-                }
-                if (!found || blk >= nblk) break;      // (the pattern's bits are visited in increasing order: nothing below nblk is left)
-            } else if (blk >= nblk) {
-                break;
-            }
+        const uint32_t per_xcd = s.xcd ? s.nparts >> 3 : 0u;
+        const uint32_t first = s.xcd ? s.part / per_xcd + 8u * (s.part % per_xcd) : s.part, stride = s.xcd ? 8u * per_xcd : s.nparts;
+        for (uint32_t blk = first; blk < nblk; blk += stride) {
             const uint32_t base0 = blk * BLK;
             uint32_t idx[U][NI];
             float dw[U];
@@ -1634,7 +1606,6 @@ __device__ __forceinline__ void own_run(float* acc, const Slice& s, const TdRecs
 #pragma unroll
             for (int u = 0; u < U; ++u)
                 own_accum_idx<NI, FB, FIXED>(idx[u], dw[u], dw[u] != 0.0f, acc, s, lo_rel, nhit_wave, D, Dc, fb_hits, (double)scale, cbits);
-            if (!s.xcd) blk += s.nparts;
         }
     } else {   // main records: this part's share of the lanes, OWN_UNROLL records per thread in flight; the loop bounds are
         // wave-uniform
@@ -1722,7 +1693,7 @@ __global__ __launch_bounds__(OWN_WG) void k_td_update_owner(float* dst, float* c
     if (fixed) {
         const float big = recs.unit ? 1.0f : __uint_as_float(*recs.dwmax);
         int e = big > 0.0f ? ilogbf(big) + 1 : 0;
-        const uint32_t part_recs = s.recs_bound + *recs.qcount;      // (the planner's bound on this part's main records + the terminal queue)
+        const uint32_t part_recs = (B + s.nparts - 1) / s.nparts + 4096u + *recs.qcount;      // (blocks of <= 4096 records, dealt round-robin)
         const uint32_t per_rec = N >= 4 ? 4u : 8u;          // adds one record can make to one slot
         const int add_bits = 32 - __clz((int)(part_recs < (1u << 28) ? per_rec * part_recs : 0x7FFFFFFFu));
         if (cdst) cbits = (uint32_t)add_bits + 1u;
@@ -2485,12 +2456,6 @@ struct g2048_ctx {
     uint32_t steps_since_read = 0;  // ... since the hit counters were last read back
     uint32_t replan_interval = 1;   // steps until the next unconditional replan: 1, 2, 4, ... replan_every after a (re)start
     double makespan_ref = 0;        // owner kernel makespan (100 MHz ticks) of the first launch under the current plan
-    // XCD balance (late round 3): how many of every 64 record blocks each XCD scans under the XCD-resident plan (sum 64; the block
-    // patterns are cut at a quarter of that: 256-block period), and the
-    // smoothed mean duration of each XCD's workgroups in the launches read back since the shares last changed
-    double xcd_share[8] = {8, 8, 8, 8, 8, 8, 8, 8};
-    double xcd_dur[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    uint32_t xcd_dur_n = 0;
     bool plan_measured = false;     // the load is a measurement (not the creation-time prior)
     hipEvent_t ev_table = nullptr;  // last table-touching launch on `stream` (contexts that share a table wait on it)
     g2048_ctx* parent = nullptr;    // owner of the shared table (g2048_create_shared); null: this context owns `w`
@@ -2500,7 +2465,6 @@ struct g2048_ctx {
     struct Knobs {
         uint32_t replan_every = 8;      // upper end of the replan schedule: the board distribution drifts with the games' age
         double imbalance = 1.15;        // replan as soon as the owner kernel's makespan exceeds this multiple of makespan_ref
-        uint32_t xcd_balance = 1;       // the XCDs' shares of the record blocks follow their measured speeds (G2048_PLAN_XCD_BALANCE)
         int feedback_each_step = 1;     // read the workgroup clocks back after every step (big batches only)
         double add_cost = 3.0, thr = 0.01, fixed_ratio = 0.25;
         int plan_feedback = 1, plan_xcd = 1, debug_plan = 0;
@@ -2594,7 +2558,6 @@ struct TableUse {
 // experiment knobs: the environment is read once, when a context is created
 void read_knobs(g2048_ctx* c) {
     g2048_ctx::Knobs& k = c->knob;
-    if (const char* e = getenv("G2048_PLAN_XCD_BALANCE")) k.xcd_balance = (uint32_t)atoi(e);
     if (const char* e = getenv("G2048_REPLAN_EVERY")) k.replan_every = (uint32_t)std::max(1, atoi(e));
     if (const char* e = getenv("G2048_PLAN_IMBALANCE")) k.imbalance = atof(e);
     if (const char* e = getenv("G2048_PLAN_EACH_STEP")) k.feedback_each_step = atoi(e);
@@ -3045,7 +3008,7 @@ int build_slices(g2048_ctx* c) {
     auto slice_of = [&](size_t k, uint32_t p, uint32_t np) {
         return Slice{chunks[k].variant, chunks[k].tlo, chunks[k].size, chunks[k].dlo, p, np, (uint32_t)k,
                      chunks[k].orb_tlo, chunks[k].orb_dlo, chunks[k].chunk0, duty[k], chunks[k].size >= OWN_SLOTS ? 15u : 14u,
-                     chunk_fixed(c, (int)chunks[k].variant) ? 1u : 0u, 0u, (c->B + np - 1) / np + 4096u, {0ull, 0ull, 0ull, 0ull}};      // (blocks of <= 4096 records, dealt round-robin)
+                     chunk_fixed(c, (int)chunks[k].variant) ? 1u : 0u, 0u};
     };
     // 0: flat plan; 1 (default where it applies): XCD-resident scan.  (Cutting the chunks into pieces packed onto the 32
     // workgroups of an XCD, a workgroup running its pieces one after the other, was tried: 0.296 -> 0.311 ms per step.)
@@ -3104,58 +3067,11 @@ int build_slices(g2048_ctx* c) {
         std::stable_sort(per_xcd.begin(), per_xcd.end(), [&](const std::pair<size_t, uint32_t>& a, const std::pair<size_t, uint32_t>& b) {
             return cost[a.first] / parts[a.first] > cost[b.first] / parts[b.first];
         });
-        // the XCDs' block patterns: of every 256 record blocks XCD x gets round(4 x xcd_share[x]) (largest remainders first,
-        // sum 256) — its own b = x (mod 8) first, then what the others leave
-        uint64_t pattern[XCDS][4] = {};
-        {
-            constexpr uint32_t PERIOD = 256;
-            uint32_t quota[XCDS], given = 0;
-            double rem[XCDS];
-            for (uint32_t x = 0; x < XCDS; ++x) {
-                const double want = c->xcd_share[x] * (PERIOD / 64.0);
-                quota[x] = (uint32_t)want;
-                rem[x] = want - quota[x];
-                given += quota[x];
-            }
-            while (given < PERIOD) {
-                uint32_t best = 0;
-                for (uint32_t x = 1; x < XCDS; ++x)
-                    if (rem[x] > rem[best]) best = x;
-                ++quota[best];
-                rem[best] = -1.0;
-                ++given;
-            }
-            uint32_t spare[PERIOD], nspare = 0;
-            for (uint32_t t = 0; t < PERIOD; ++t) {
-                if (quota[t % XCDS]) {
-                    pattern[t % XCDS][t >> 6] |= 1ull << (t & 63u);
-                    --quota[t % XCDS];
-                } else {
-                    spare[nspare++] = t;
-                }
-            }
-            for (uint32_t i = 0; i < nspare; ++i) {
-                uint32_t best = 0;
-                for (uint32_t x = 1; x < XCDS; ++x)
-                    if (quota[x] > quota[best]) best = x;
-                pattern[best][spare[i] >> 6] |= 1ull << (spare[i] & 63u);
-                --quota[best];
-            }
-        }
-        const uint32_t nblk = (c->B + 4095u) / 4096u;           // (OWN_WG x G2048_OWN_U records per block: own_run)
-        static_assert(OWN_WG * G2048_OWN_U == 4096, "the planner counts record blocks of 4 096");
         for (const auto& kj : per_xcd)
             for (uint32_t x = 0; x < XCDS; ++x)
             {
-                const uint32_t np = parts[kj.first];
-                Slice sl = slice_of(kj.first, x * np + kj.second, XCDS * np);
+                Slice sl = slice_of(kj.first, x * parts[kj.first] + kj.second, XCDS * parts[kj.first]);
                 sl.xcd = 1u;
-                for (int q = 0; q < 4; ++q) sl.blocks[q] = pattern[x][q];
-                uint32_t mine = 0, seen = 0;                    // the blocks own_run will hand this part
-                for (uint32_t b = 0; b < nblk; ++b)
-                    if ((pattern[x][(b & 255u) >> 6] >> (b & 63u)) & 1ull)
-                        if (seen++ % np == kj.second) ++mine;
-                sl.recs_bound = mine * 4096u + 4096u;
                 v.push_back(sl);
             }
         for (size_t k = 0; k < nc; ++k)                                     // the flat ones behind the groups of 8
@@ -3265,8 +3181,6 @@ int replan(g2048_ctx* c) {
         std::vector<double> sum(c->n_chunks, 0.0);
         std::vector<uint32_t> cnt(c->n_chunks, 0);
         uint64_t first = ~0ull, last = 0;
-        double xsum[XCDS] = {};
-        uint32_t xcnt[XCDS] = {};
         for (uint32_t i = 0; i < c->n_slices; ++i) {
             const uint64_t a = clk[2 * i], b = clk[2 * i + 1];
             if (b <= a || b - a > 100000000ull || c->plan[i].chunk >= c->n_chunks) continue;      // (never launched / garbage)
@@ -3274,19 +3188,6 @@ int replan(g2048_ctx* c) {
             ++cnt[c->plan[i].chunk];
             first = a < first ? a : first;
             last = b > last ? b : last;
-            if (c->plan[i].xcd) {           // (workgroup i runs on XCD i % 8; every XCD has the same mix of chunks and parts)
-                xsum[i % XCDS] += (double)(b - a);
-                ++xcnt[i % XCDS];
-            }
-        }
-        bool all_xcds = true;
-        for (uint32_t x = 0; x < XCDS; ++x) all_xcds = all_xcds && xcnt[x] > 0;
-        if (all_xcds) {
-            for (uint32_t x = 0; x < XCDS; ++x) {
-                const double d = xsum[x] / xcnt[x];
-                c->xcd_dur[x] = c->xcd_dur_n ? 0.5 * c->xcd_dur[x] + 0.5 * d : d;
-            }
-            ++c->xcd_dur_n;
         }
         if (last > first && last - first < 100000000ull) makespan = (double)(last - first);
         if (c->work.size() != c->n_chunks) c->work.assign(c->n_chunks, 0.0);
@@ -3308,26 +3209,6 @@ int replan(g2048_ctx* c) {
                 c->makespan_ref * 0.01, due ? " due" : "", skew ? " skew" : "");
     if (!due && !skew) return G2048_OK;
     if (due) c->replan_interval = std::min(c->replan_interval * 2u, std::max(1u, c->knob.replan_every));
-    // XCD balance: an XCD that took longer than the others for its share of the record blocks gets a smaller one (half of the
-    // way to what the measured speeds ask for; at least 4 of every 64 blocks each)
-    if (c->knob.xcd_balance && c->xcd_dur_n >= 2) {
-        double speed[XCDS], total = 0;
-        for (uint32_t x = 0; x < XCDS; ++x) {
-            speed[x] = c->xcd_share[x] / (c->xcd_dur[x] > 1.0 ? c->xcd_dur[x] : 1.0);
-            total += speed[x];
-        }
-        double norm = 0;
-        for (uint32_t x = 0; x < XCDS; ++x) {
-            const double target = 64.0 * speed[x] / total;
-            c->xcd_share[x] = std::min(16.0, std::max(4.0, 0.5 * c->xcd_share[x] + 0.5 * target));
-            norm += c->xcd_share[x];
-        }
-        for (uint32_t x = 0; x < XCDS; ++x) c->xcd_share[x] *= 64.0 / norm;
-        c->xcd_dur_n = 0;
-        if (c->knob.debug_plan)
-            fprintf(stderr, "[g2048 feedback] XCD shares of 64 blocks: %.1f %.1f %.1f %.1f %.1f %.1f %.1f %.1f\n", c->xcd_share[0], c->xcd_share[1], c->xcd_share[2],
-                    c->xcd_share[3], c->xcd_share[4], c->xcd_share[5], c->xcd_share[6], c->xcd_share[7]);
-    }
     return build_slices(c);
 }
 
@@ -3482,9 +3363,9 @@ int launch_td_step(g2048_ctx* c, float alpha, hipEvent_t ev = nullptr, hipEvent_
         bool one_pass = false;
         const bool hex_binned = c->n == 6 && c->knob.hex_bins && c->hex.pairs;
         if (c->update_rule == 1) {
-            uint32_t most = 0;          // the longest record range of a workgroup
-            for (const Slice& sl : c->plan) most = sl.recs_bound > most ? sl.recs_bound : most;
-            const uint64_t adds = (uint64_t)(c->n >= 4 ? 4 : 8) * ((uint64_t)most + 4096u);
+            uint32_t min_parts = ~0u;
+            for (const Slice& sl : c->plan) min_parts = sl.nparts < min_parts ? sl.nparts : min_parts;
+            const uint64_t adds = (uint64_t)(c->n >= 4 ? 4 : 8) * ((B + min_parts - 1) / (min_parts ? min_parts : 1) + 8192);
             one_pass = c->knob.mean_one_pass && !c->plan.empty() && adds < (1ull << 21);
             TdRecs ones = recs;
             ones.unit = 1;
