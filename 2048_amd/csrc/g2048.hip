@@ -2147,8 +2147,8 @@ __global__ __launch_bounds__(WG) void k_hex_apply(float* w, float* dacc, float* 
 //                  lane of every key present then reserves the tile's share of the key's bucket with ONE global atomic
 //                  (<= 256 atomics per key and sort, however skewed the keys) and passes the reserved offset on to the
 //                  others through LDS;
-//   k_sort_scan    exclusive scan of the 65 536 bucket sizes (one workgroup), counters cleared for the next sort;
-//   k_sort_scatter perm[bucket start + offset] = position.
+//   k_sort_scan    exclusive scan of the 65 536 bucket sizes (64 independent workgroups);
+//   k_sort_scatter perm[bucket start + offset] = position; counters cleared for the next sort.
 // Inside a bucket the order is that of the tiles' reservations, i.e. not reproducible from run to run; nothing observable
 // depends on it (the lanes' games do not, the fixed-point sums of the update do not).
 constexpr uint32_t SORT_TILE = 5;               // default threshold (G2048_SORT_TILE): key bit set for tiles above 2^5
@@ -2233,52 +2233,38 @@ __global__ __launch_bounds__(SORT_TPB) void k_sort_count(const uint4* boards, ui
     }
 }
 
-// start[k] = number of lanes with a smaller key; cnt is left zeroed for the next sort.  One workgroup, thread t owns the 64
-// consecutive buckets [64 t, 64 t + 64): a pass that only sums them (16 independent 16-byte loads), a scan of the 1 024
-// sums, and a second pass over the same 256 KB (from L2) that writes the starts.  (A row-wise form — 64 coalesced rows
-// per wave, a wave scan per row — was a chain of 64 x 6 dependent cross-lane shuffles: 57 us.)
-__global__ __launch_bounds__(SORT_TPB) void k_sort_scan(uint32_t* cnt, uint32_t* start) {
-    constexpr uint32_t PER = SORT_KEYS / SORT_TPB, VEC = PER / 4;
-    __shared__ uint32_t wave_sum[SORT_TPB / 64];
-    uint4* const mine = reinterpret_cast<uint4*>(cnt + threadIdx.x * PER);
-    uint32_t sum = 0;
-#pragma unroll
-    for (uint32_t j = 0; j < VEC; ++j) {
-        const uint4 v = mine[j];
-        sum += v.x + v.y + v.z + v.w;
-    }
-    uint32_t incl = sum;                                    // inclusive scan of the threads' sums: inside the wave, then over the 16 waves
+// start[k] = number of lanes with a smaller key.  64 workgroups, one per 1 024 buckets, none waiting for another: each first adds
+// up everything in front of its segment (the whole counter array is 256 KB and sits in L2: at most 63 coalesced loads per
+// thread), then scans its own 1 024 counters.  (Round 3's first form was one workgroup walking all 65 536 buckets: 73 us on
+// the side stream, 3.4 % of all kernel time for 1/256 of the chip.)  The counters are cleared by k_sort_scatter, which runs
+// behind this kernel on the same stream — here every workgroup still reads the others' segments.
+constexpr uint32_t SCAN_SEG = SORT_TPB;
+__global__ __launch_bounds__(SORT_TPB) void k_sort_scan(const uint32_t* cnt, uint32_t* start) {
+    __shared__ uint32_t wave_sum[SORT_TPB / 64], wave_front[SORT_TPB / 64];
+    const uint32_t seg = blockIdx.x * SCAN_SEG, lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    uint32_t front = 0;                                     // this thread's share of the buckets in front of the segment
+    for (uint32_t i = threadIdx.x; i < seg; i += SORT_TPB) front += cnt[i];
+    const uint32_t mine = cnt[seg + threadIdx.x];
+    uint32_t incl = mine;                                   // inclusive scan inside the wave
 #pragma unroll
     for (uint32_t d = 1; d < 64; d <<= 1) {
         const uint32_t up = __shfl_up(incl, d, 64);
-        if ((threadIdx.x & 63u) >= d) incl += up;
+        if (lane >= d) incl += up;
     }
-    if ((threadIdx.x & 63u) == 63u) wave_sum[threadIdx.x >> 6] = incl;
+#pragma unroll
+    for (uint32_t d = 32; d > 0; d >>= 1) front += __shfl_down(front, d, 64);
+    if (lane == 63u) wave_sum[wv] = incl;
+    if (lane == 0u) wave_front[wv] = front;
     __syncthreads();
-    uint32_t base = incl - sum;
-    for (uint32_t wv = 0; wv < (threadIdx.x >> 6); ++wv) base += wave_sum[wv];
-    uint4* const out = reinterpret_cast<uint4*>(start + threadIdx.x * PER);
-#pragma unroll
-    for (uint32_t q = 0; q < VEC; q += 4) {
-        uint4 v[4];
-#pragma unroll
-        for (uint32_t j = 0; j < 4; ++j) v[j] = mine[q + j];
-#pragma unroll
-        for (uint32_t j = 0; j < 4; ++j) {
-            uint4 o;
-            o.x = base; base += v[j].x;
-            o.y = base; base += v[j].y;
-            o.z = base; base += v[j].z;
-            o.w = base; base += v[j].w;
-            out[q + j] = o;
-            mine[q + j] = make_uint4(0, 0, 0, 0);
-        }
-    }
+    uint32_t base = 0;
+    for (uint32_t k = 0; k < SORT_TPB / 64; ++k) base += wave_front[k] + (k < wv ? wave_sum[k] : 0u);
+    start[seg + threadIdx.x] = base + incl - mine;
 }
 
-__global__ __launch_bounds__(WG) void k_sort_scatter(const uint16_t* key16, const uint32_t* off, const uint32_t* start, uint32_t B, uint32_t* perm) {
+__global__ __launch_bounds__(WG) void k_sort_scatter(const uint16_t* key16, const uint32_t* off, const uint32_t* start, uint32_t B, uint32_t* perm, uint32_t* cnt) {
     const uint32_t i = blockIdx.x * WG + threadIdx.x;
     if (i < B) perm[start[key16[i]] + off[i]] = i;
+    if (i < SORT_KEYS) cnt[i] = 0;                          // (the bucket counters, for the next sort: k_sort_count adds into them)
 }
 
 struct CarrySet {       // the `state` of QAgent.episode and its orbit indices (prev[cur], oidx[cur])
@@ -2664,8 +2650,8 @@ int lane_sort_permutation(g2048_ctx* c, bool side) {
         HIP_TRY(c, hipStreamWaitEvent(c->sort_stream, c->ev_sort_go, 0));
         st = c->sort_stream;
     }
-    k_sort_scan<<<1, SORT_TPB, 0, st>>>(c->sort_cnt, c->sort_start);
-    k_sort_scatter<<<grid_for(c->B), WG, 0, st>>>(c->sort_key16, c->sort_off, c->sort_start, c->B, c->sort_perm);
+    k_sort_scan<<<SORT_KEYS / SCAN_SEG, SORT_TPB, 0, st>>>(c->sort_cnt, c->sort_start);
+    k_sort_scatter<<<grid_for(c->B > SORT_KEYS ? c->B : SORT_KEYS), WG, 0, st>>>(c->sort_key16, c->sort_off, c->sort_start, c->B, c->sort_perm, c->sort_cnt);
     if (side) {
         HIP_TRY(c, hipEventRecord(c->ev_sort_done, c->sort_stream));
         c->sort_issued = true;
