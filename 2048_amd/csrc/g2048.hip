@@ -1755,10 +1755,13 @@ __device__ __forceinline__ void mirror_stats(const StatMirror& m) {
     if (blockIdx.x >= nblk) return;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < m.words) m.dst[i] = __hip_atomic_load(&m.src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (written by the previous kernel: bypass a stale L1 line)
-    __threadfence_system();
+    // (the stores go straight to pinned, uncached host memory: what is needed in front of the announcement is that they have been
+    // PERFORMED — a wait — not a system-scope fence, which on this chip writes back and invalidates the XCD's L2 in the middle of
+    // the step)
+    __threadfence_block();
     __syncthreads();
     // the block that finishes last announces the set (a counter that is never reset: every mirroring launch adds nblk to it)
-    if (threadIdx.x == 0 && atomicAdd(m.done, 1u) % nblk == nblk - 1u) __hip_atomic_store(&m.dst[m.words], m.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x == 0 && atomicAdd(m.done, 1u) % nblk == nblk - 1u) __hip_atomic_store(&m.dst[m.words], m.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // table_i[perm_i(k)] += v for every member i of the orbit; `dacc` (may be null) mirrors the add (g2048_delta_begin)
