@@ -317,14 +317,21 @@ def test_td_mean_rule_vs_oracle(n):
     eng.close()
 
 
-def test_td_large_batch_vs_oracle_through_replans():
+@pytest.mark.parametrize('poll', [1, 0])
+def test_td_large_batch_vs_oracle_through_replans(poll, monkeypatch):
     """131 072 lanes, n = 5: the size at which the XCD-resident plan and the measured-cost replans (every 8 steps) are
-    in use; every step is still checked against the float64 oracle."""
+    in use; every step is still checked against the float64 oracle.  Both ways the planner's statistics reach the host: the
+    sequence word the apply kernel stores behind them (default) and the event behind the apply kernel (G2048_PLAN_POLL=0);
+    a burst of steps without an accessor in between, so that the host runs ahead of the device, sits in the middle."""
+    monkeypatch.setenv('G2048_PLAN_POLL', str(poll))
     n, B = 5, 1 << 17
     eng = Engine(B, n=n, seed=77)
     eng.set_auto_reset(False)
     eng.step_random(40)
     for t in range(18):
+        if t == 9:
+            eng.set_weights(formulas.weights(n, scale=2.0 ** -6))
+            eng.td_steps(formulas.exact_alpha(n) * 2.0 ** -12, 24)
         helpers.check_td_step(eng, n, formulas.exact_alpha(n), formulas.weights(n, scale=2.0 ** -(4 + t % 4)))
     plan = eng.debug_owner_plan()
     assert len(plan) % 8 == 0                                                # parts come in multiples of the 8 XCDs
