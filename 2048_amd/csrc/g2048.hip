@@ -3143,7 +3143,10 @@ int replan(g2048_ctx* c) {
     if (c->mirror_want) {
         const uint32_t want = c->mirror_want;
         c->mirror_want = 0;
-        if (!mirror_arrived(c, want)) HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (!mirror_arrived(c, want)) {         // (never seen; if it happens the context goes back to the event for good)
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            c->knob.plan_poll = 0;
+        }
     } else {
         HIP_TRY(c, hipEventSynchronize(c->ev_plan));
     }
