@@ -3286,10 +3286,11 @@ int launch_td_step(g2048_ctx* c, float alpha, hipEvent_t ev = nullptr, hipEvent_
             if (int rc = stats_readback(c)) return rc;
     }
     // lane re-ordering (LaneSort): when due, this step's k_td_play reads the lanes through the sorted permutation
+    // (n = 3 since late round 3: nothing for a fresh agent, -9 % per step for a trained one; n = 2 has no table read outside LDS)
     const uint32_t* perm = nullptr;
     LaneSet lin = current_set(c), lout = lin;
     bool start_sort = false;            // take the keys behind this step's k_td_play and sort them on the side stream
-    if (c->sort_every && c->n >= 4 && B >= c->knob.sort_min_batch) {
+    if (c->sort_every && c->n >= 3 && B >= c->knob.sort_min_batch) {
         if (c->sort_pending) {
             if (c->sort_wait == 0 || --c->sort_wait == 0) {
                 HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_sort_done, 0));
@@ -3535,6 +3536,8 @@ static int create_impl(int device, uint32_t batch, int n_tuple, uint64_t seed, u
         hipEventCreateWithFlags(&c->ev_table, hipEventDisableTiming) != hipSuccess)
         return bail(G2048_ERR_HIP);
     read_knobs(c);
+    // (n = 3: its LDS set holds the entries whose three cells are all below 8, so "big" for the lane order starts at 256 there)
+    if (n_tuple == 3 && !getenv("G2048_SORT_TILE")) c->knob.sort_tile = 7;
     const size_t B = batch;
     if ((rc = dalloc(c, &c->boards, B)) || (rc = dalloc(c, &c->scores, B)) || (rc = dalloc(c, &c->rng, B)) ||
         (rc = dalloc(c, &c->prev[0], B)) || (rc = dalloc(c, &c->prev[1], B)) || (rc = dalloc(c, &c->label, B)) ||

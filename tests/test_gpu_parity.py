@@ -364,7 +364,7 @@ def test_td_hot_set_path_vs_oracle(n, B, monkeypatch):
 
 
 @pytest.mark.parametrize('lag', [2, 0])
-@pytest.mark.parametrize('n', [4, 5, 6])
+@pytest.mark.parametrize('n', [3, 4, 5, 6])
 def test_lane_sort_is_invisible(n, lag, monkeypatch):
     """g2048_set_lane_sort: lanes re-ordered by their big-tile pattern every few steps (k_td_play reads them through the
     sorted permutation).  Every step is still the oracle's step, lane for lane (the accessors restore the identity
