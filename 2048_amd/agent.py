@@ -209,7 +209,7 @@ class QAgent:
             return None
         # (weights handed over before the first use of the device can be read back — and pickled — without one)
         flat = self._pending_weights if self._engine is None else self.engine.get_weights()
-        offs, sizes = feature_layout(self.n)
+        offs, sizes = feature_layout(self.n, getattr(self._engine, 'backend', None))
         return [flat[o:o + s] for o, s in zip(offs, sizes)]
 
     @weights.setter
@@ -677,10 +677,9 @@ class QAgent:
             else:
                 game = self._game_from_log(eng, lane, 0, length, score)
                 game.moves.pop()                               # trial_run ends without the -1 that episode() appends
-            if game_init is not None:                          # the games continue game_init's record
-                game.starting_position = np.array(game_init.starting_position, np.int32)
-                game.moves, game.tiles = list(game_init.moves) + game.moves, list(game_init.tiles) + game.tiles
-                game.odometer += game_init.odometer
+            # (game_init: every game is `game_init.copy()` = Game(score, row), r_learning.py:363 / game_logic.py:69-70 — a fresh
+            # record from that position: odometer 0, only the trial's own moves and tiles, starting_position = game_init.row;
+            # which is what the device's record holds, its start being the board set above)
             games.append(game)
         eng.close()
         return games
@@ -748,11 +747,7 @@ class QAgent:
             game = Game(score=int(scores[g]), row=boards[g].reshape(4, 4).astype(np.int32))
             game.starting_position = start[g].reshape(4, 4).astype(np.int32)
             game.moves, game.tiles, game.odometer = moves[g], tiles[g], len(moves[g])
-            if game_init is not None:
-                game.starting_position = np.array(game_init.starting_position, np.int32)
-                game.moves, game.tiles = list(game_init.moves) + game.moves, list(game_init.tiles) + game.tiles
-                game.odometer += game_init.odometer
-            games.append(game)
+            games.append(game)             # (game_init: a fresh record from game_init.row, as game_init.copy() is — see _trial_batched)
         return games
 
 

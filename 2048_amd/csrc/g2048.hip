@@ -26,6 +26,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
@@ -1744,8 +1745,8 @@ struct StatMirror {
     const uint32_t* src;    // device: statbuf
     uint32_t* dst;          // pinned host memory (device-visible); null: no mirror this step
     uint32_t words;
-    uint32_t seq;           // stored at dst[words] once the statistics are in host memory
-    uint32_t* done;         // device counter of the mirroring blocks
+    uint32_t seq;           // stored at dst[words] once the statistics are in host memory; dst[words + 1] = their checksum
+    unsigned long long* done;   // device: {checksum so far : 32 | mirroring blocks finished : 32} of THIS launch (the last block clears it)
 };
 // The first mirror_blocks() blocks of an apply launch do nothing else (the system-scope fence waits for the stores' trip over
 // PCIe, ~2 us: inside a block that also has table work it lengthened the kernel by that much); the others see their index shifted.
@@ -1753,15 +1754,39 @@ __host__ __device__ __forceinline__ uint32_t mirror_blocks(const StatMirror& m) 
 __device__ __forceinline__ void mirror_stats(const StatMirror& m) {
     const uint32_t nblk = mirror_blocks(m);     // one word per thread
     if (blockIdx.x >= nblk) return;
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < m.words) m.dst[i] = __hip_atomic_load(&m.src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (written by the previous kernel: bypass a stale L1 line)
-    // (the stores go straight to pinned, uncached host memory: what is needed in front of the announcement is that they have been
-    // PERFORMED — a wait — not a system-scope fence, which on this chip writes back and invalidates the XCD's L2 in the middle of
-    // the step)
-    __threadfence_block();
+    __shared__ uint32_t part;
+    if (threadIdx.x == 0) part = 0;
     __syncthreads();
-    // the block that finishes last announces the set (a counter that is never reset: every mirroring launch adds nblk to it)
-    if (threadIdx.x == 0 && atomicAdd(m.done, 1u) % nblk == nblk - 1u) __hip_atomic_store(&m.dst[m.words], m.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t v = 0;
+    if (i < m.words) {
+        v = __hip_atomic_load(&m.src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (written by the previous kernel: bypass a stale L1 line)
+        m.dst[i] = v;
+    }
+    uint32_t sum = v;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off);
+    if ((threadIdx.x & 63u) == 0) atomicAdd(&part, sum);
+    // The stores go straight to pinned, uncached host memory.  What has to stand between them and the announcement is that they
+    // have been PERFORMED: every storing wave waits for its stores' acknowledgements here (a workgroup-scope fence emits no wait
+    // on gfx950 — round 3 had only that, the advisor's finding; a system-scope release fence would also write back and
+    // invalidate the XCD's L2 in the middle of the step, +1.2 us, profiles/r03_experiments.txt item 23b).  The wait orders the
+    // hardware; for whatever the memory model leaves open the set carries a checksum, which the host verifies before it
+    // trusts the statistics (mirror_arrived).  tools/check_codeobj.py checks that this wait is in the code object.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // The block that finishes last announces the set.  One 64-bit atomic carries the block's checksum part and its "done" tick,
+    // so the last block sees every part; it is issued behind the wait above (in-order issue, "memory" clobber for the compiler).
+    if (threadIdx.x == 0) {
+        const unsigned long long old = atomicAdd(m.done, ((unsigned long long)part << 32) | 1ull);
+        if ((uint32_t)old == nblk - 1u) {
+            const uint32_t total = (uint32_t)(old >> 32) + part;
+            *m.done = 0ull;          // (nobody else touches it before the next mirroring launch, which is behind this one on the stream)
+            // checksum first, sequence word second: both uncached stores of one thread to one 8-byte-aligned pair, issued as ONE store
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(m.dst + m.words), (unsigned long long)total << 32 | m.seq, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 // table_i[perm_i(k)] += v for every member i of the orbit; `dacc` (may be null) mirrors the add (g2048_delta_begin)
@@ -2854,6 +2879,7 @@ int find_orbits(g2048_ctx* c) {
 // boards put almost every add into the low half of each table, a trained agent's boards do not.
 constexpr uint32_t MAX_SLICES = 1024, HITS_CAP = 128;
 constexpr size_t STAT_BYTES = HITS_CAP * 4 + 2 * MAX_SLICES * 8;
+static_assert(STAT_BYTES % 8 == 0, "mirror_stats stores {sequence, checksum} as one aligned 8-byte word behind the statistics");
 constexpr uint32_t WG_BUDGET = 250;
 constexpr uint32_t XCDS = 8, CUS_PER_XCD = 32;
 
@@ -3120,11 +3146,17 @@ int stats_readback(g2048_ctx* c) {
 // wait until the apply kernel with sequence number `want` has stored its statistics (it is queued in front of the k_td_play
 // just launched: a fraction of a step away).  Bounded: a lost store must not hang the host.
 bool mirror_arrived(const g2048_ctx* c, uint32_t want) {
-    const volatile uint32_t* seq = reinterpret_cast<const volatile uint32_t*>(c->h_stat + STAT_BYTES);
+    const volatile unsigned long long* tag = reinterpret_cast<const volatile unsigned long long*>(c->h_stat + STAT_BYTES);
+    const uint32_t* h = reinterpret_cast<const uint32_t*>(c->h_stat);
     for (uint64_t spin = 0; spin < (1ull << 26); ++spin) {
-        if ((int32_t)(*seq - want) >= 0) {
+        const unsigned long long t = *tag;          // {checksum : 32 | sequence number : 32}, one 8-byte store of the device
+        if ((int32_t)((uint32_t)t - want) >= 0) {
             __atomic_thread_fence(__ATOMIC_ACQUIRE);
-            return true;
+            // trust the statistics only if they add up to the checksum that came with the sequence number: a set whose words
+            // were still on their way when the tag landed does not (then keep polling — it is a fraction of a microsecond away)
+            uint32_t sum = 0;
+            for (size_t i = 0; i < STAT_BYTES / 4; ++i) sum += h[i];
+            if (sum == (uint32_t)(t >> 32) || (uint32_t)t != want) return true;      // (a newer set than the one waited for: the caller reads what is there)
         }
         if ((spin & 1023u) == 1023u) std::this_thread::yield();
     }
@@ -3207,16 +3239,21 @@ int replan(g2048_ctx* c) {
 }
 
 // a kernel that takes more than 64 KB of dynamic LDS has to be told so once (per process: the attribute belongs to the function)
+// (keyed on the kernel's address and the device — every k_td_play_* instantiation has the same function TYPE, so a
+// per-type flag would cover only the first of them: the advisor's round-3 finding)
 template <class K>
 void allow_dynamic_lds(K kernel, uint32_t bytes) {
-    static bool done[64] = {};             // per device: the attribute is set on the current device's copy of the function
+    if (bytes <= 65536u) return;
+    static std::mutex mu;
+    static std::vector<std::pair<const void*, int>> done;
     int dev = 0;
     (void)hipGetDevice(&dev);
-    dev = dev >= 0 && dev < 64 ? dev : 0;
-    if (bytes > 65536u && !done[dev]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-        done[dev] = true;
-    }
+    const std::pair<const void*, int> key{reinterpret_cast<const void*>(kernel), dev};
+    std::lock_guard<std::mutex> lock(mu);
+    if (std::find(done.begin(), done.end(), key) != done.end()) return;
+    const hipError_t e = hipFuncSetAttribute(key.first, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) fprintf(stderr, "[g2048] hipFuncSetAttribute(MaxDynamicSharedMemorySize = %u): %s\n", bytes, hipGetErrorString(e));
+    done.push_back(key);
 }
 
 // workgroups of k_td_play: as many as are resident at once (occupancy x CUs), or fewer if the batch is small
@@ -3384,7 +3421,7 @@ int launch_td_step(g2048_ctx* c, float alpha, hipEvent_t ev = nullptr, hipEvent_
         if (ev_tail) (void)hipEventRecord(ev_tail, c->stream);
         const StatMirror sm{reinterpret_cast<const uint32_t*>(c->statbuf), c->n >= 4 ? reinterpret_cast<uint32_t*>(c->h_stat_dev) : nullptr,
                             (uint32_t)(STAT_BYTES / 4), c->n >= 4 ? ++c->mirror_seq : 0u,
-                            reinterpret_cast<uint32_t*>(c->statbuf + STAT_BYTES)};
+                            reinterpret_cast<unsigned long long*>(c->statbuf + STAT_BYTES)};
         OrbitTable ot = c->orbits;
         if (hex_binned) ot.total = c->owned_total;      // the f_6 orbit tables are applied chunk by chunk (k_hex_apply)
         if (c->update_rule == 1)

@@ -17,15 +17,17 @@ def _buf(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
 
-def table_slots(n):
-    return int(_lib.load().g2048_table_slots(n))      # (geometry: the same in both libraries)
+def table_slots(n, backend=None):
+    """(geometry: the same in both libraries; `backend` says which one answers — an explicit Engine(backend='cpu') must not
+    need the other library)"""
+    return int(_lib.load(backend).g2048_table_slots(n))
 
 
-def feature_layout(n):
+def feature_layout(n, backend=None):
     F = NUM_FEAT[n]
     offs = np.zeros(F, np.int64)
     sizes = np.zeros(F, np.int64)
-    check(_lib.load().g2048_feature_layout(n, _buf(offs), _buf(sizes)))
+    check(_lib.load(backend).g2048_feature_layout(n, _buf(offs), _buf(sizes)))
     return offs, sizes
 
 
@@ -38,11 +40,9 @@ class Engine:
             n, device, backend = share_table_of.n, share_table_of.device, share_table_of.backend
         self.backend = backend or _lib.default_backend()
         self.lib = _lib.load(self.backend)
-        if share_table_of is not None:
-            pass
         self.batch, self.n, self.seed, self.lane0, self.device = int(batch), int(n), int(seed), int(lane0), int(device)
         self.num_feat = NUM_FEAT.get(self.n, 0)
-        self.slots = table_slots(self.n) if self.n else 0
+        self.slots = table_slots(self.n, self.backend) if self.n else 0
         self.parent = share_table_of                      # keeps the table's owner alive
         ctx = ctypes.c_void_p()
         if share_table_of is None:
@@ -297,8 +297,8 @@ class Engine:
 
     # native RCCL path (include/g2048.h, multi-GPU)
     @staticmethod
-    def comm_unique_id():
-        lib = _lib.load()
+    def comm_unique_id(backend=None):
+        lib = _lib.load(backend)
         buf = (ctypes.c_uint8 * _lib.COMM_ID_BYTES)()
         check(lib.g2048_comm_unique_id(buf))
         return bytes(buf)

@@ -597,6 +597,21 @@ def main():
                                            'all_links_direct': (2 * payload / world / link * 1e3) if world > 1 else 0.0}}
         if seen[1] != world:
             raise SystemExit(f'[bench] the communicator reports {seen[1]} ranks, expected {world}')
+        # what every rank ran on, gathered: its lane shard (lane0 = rank x B: episodes are sharded, nothing else is) and two
+        # checksums of its table after the last exchange — the replicas must be identical
+        import torch
+        wflat = eng.get_weights().astype(np.float64)
+        mine = [float(rank * B), float(wflat.sum()), float(np.dot(wflat, wflat))]
+        del wflat
+        box = torch.zeros((world, 3), dtype=torch.float64, device='cuda' if args.backend == 'nccl' else 'cpu')
+        box[rank] = torch.tensor(mine, dtype=torch.float64)
+        dist.all_reduce(box)
+        box = box.cpu().numpy()
+        comm['lane0_per_rank'] = [int(x) for x in box[:, 0]]
+        comm['table_checksums_per_rank'] = [[float(a), float(b)] for a, b in box[:, 1:]]
+        comm['replicas_identical'] = bool((box[:, 1:] == box[0, 1:]).all())
+        if not comm['replicas_identical'] or len(set(comm['lane0_per_rank'])) != world:
+            raise SystemExit(f'[bench] replicas differ or lane shards overlap: {comm["lane0_per_rank"]} {comm["table_checksums_per_rank"]}')
 
     mean_line = None
     if world == 1 and not dist and args.rule == 'sum' and not args.no_mean_line:
@@ -643,8 +658,9 @@ def main():
             'ms_per_step': ms_step,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'u8 boards / int32 scores / f32 weights', 'data': 'synthetic',
-            'config': {'workload': f'BASELINE config 4: full TD(0) loop, {n}-tuple table ({eng.slots * 4} B), '
-                                   f'{B} concurrent episodes per GPU, auto-reset',
+            'config': {'workload': (f'BASELINE config 5: {world} x MI355X data-parallel TD(0) training, 6-tuple table ({eng.slots * 4} B), ' if n == 6 and world > 1 else
+                                    f'BASELINE config 4: full TD(0) loop, {n}-tuple table ({eng.slots * 4} B), ')
+                                   + f'{B} concurrent episodes per GPU, auto-reset',
                        'batch_per_gpu': B, 'n_tuple': n, 'alpha_effective': alpha, 'update_rule': args.rule,
                        'parallelism': f'episodes sharded over {world} GPU(s)' + (f', weight-delta all-reduce every {args.epoch} steps via {comm_kind}' if sync else '')},
             'protocol': {'conditioning_steps': args.condition, 'repeats': len(times), 'statistic': 'median',

@@ -142,11 +142,12 @@ int g2048_update(g2048_ctx* ctx, const uint8_t* states /* [count][16] */, const 
  * the device: it reads the update kernel's load statistics back after every step to keep its work plan balanced). */
 int g2048_td_steps(g2048_ctx* ctx, float alpha, uint32_t nsteps);
 /* Lane order in memory.  k_td_play is bound by the L1 misses of its table gathers, and lanes whose big tiles sit in the
- * same cells touch the same cache lines: with every > 0 each `every`-th TD step re-orders the lanes by their big-tile
- * pattern (a hand-written counting sort on one key bit per cell, three launches; the step reads its lanes through the
- * permutation).  Invisible through this ABI — every entry
- * point that addresses lanes by index restores the identity order first (one copy pass) — and to the results: a lane's
- * game does not depend on where it sits.  Default 16; 0: never.  Batches below 2^17 lanes and n < 4 keep their order. */
+ * same cells with the same values touch the same cache lines: with every > 0 each `every`-th TD step re-orders the lanes by a
+ * 16-bit key — a hash of `value >> 1` of every tile above a threshold (32; n = 3: 128), by cell (G2048_SORT_VALUES=0: one bit
+ * per cell) — with a hand-written counting sort, three launches; the step that applies it reads its lanes through the
+ * permutation.  Invisible through this ABI — every entry point that addresses lanes by index restores the identity order first
+ * (one copy pass) — and to the results: a lane's game does not depend on where it sits.  Default 8 (G2048_SORT_EVERY); 0: never.
+ * Batches below 2^17 lanes (G2048_SORT_MIN) and n = 2 keep their order. */
 int g2048_set_lane_sort(g2048_ctx* ctx, uint32_t every);
 /* test hook: the permutation the re-order would apply to the current boards (position i takes the lane at perm[i]) and the
  * key of every position; the lane order is left alone */

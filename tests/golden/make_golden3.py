@@ -7,6 +7,7 @@
   trial.npz           QAgent.trial (r_learning.py:348-406) -> Game.trial_run (game_logic.py:170-183), depth 0, 8 games with
                       dyadic n=4 weights; game g draws its tiles from lane LANE0 + g of the device RNG spec.  Per game (in
                       the order trial returns them: best first): score, odometer, final row, starting position, moves, tiles.
+  trial_init.npz      the same with game_init = a mid-game position (r_learning.py:363: game_init.copy()), 6 games.
   built_pickles.npz   what the REFERENCE makes of pickles written by THIS build (tests/golden/built_*.pkl, produced by
                       make_built_pickles.py with 2048_amd's own classes): the agent's evaluate() on golden boards after the
                       reference's own load path (pickle.load + np_to_list, r_learning.py:189-200), attribute values, and the
@@ -82,6 +83,50 @@ def trial(gl, rl):
     real_print(f'  trial: scores {[g.score for g in results]}, moves {[g.odometer for g in results]}')
 
 
+def trial_with_game_init(gl, rl):
+    """QAgent.trial(game_init=...) (r_learning.py:362-365): every game is `game_init.copy()` = Game(score, row) — a FRESH record
+    (odometer 0, no moves, no tiles, starting_position = game_init.row) that continues from a mid-game position.  Game g draws
+    its tiles from lane LANE0 + g of the RNG spec, behind the two draws a fresh game of that lane would have used for its
+    first tiles (the device seeds a lane by starting a game in it; the position is then set from game_init)."""
+    agent, _ = dyadic_agent(rl.QAgent, TRIAL_N, 2.0 ** -6)
+    boards = np.load(os.path.join(HERE, 'features.npz'))['boards']
+    pick = next(b for b in boards if b.max() == 7 and (b == 0).sum() >= 4)        # a mid-game position, some room left
+    game_init = gl.Game(score=1500, row=pick.astype(np.int32))
+    game_init.odometer, game_init.moves, game_init.tiles = 3, [0, 1, 2], [(1, (0, 0))] * 3          # a prefix the copies must NOT inherit
+    shim = LaneShim(TRIAL_SEED + 1, TRIAL_LANE0)
+    gl.random = shim
+    real_init = gl.Game.__init__
+
+    def init(self, score=0, row=None, file=None):
+        if row is not None:                                 # game_init.copy()
+            shim.new_game()
+            for cells in (16, 15):                          # the lane's own first two tiles, not used
+                shim.randrange(10)
+                shim.choice(list(range(cells)))
+        real_init(self, score=score, row=row, file=file)
+    gl.Game.__init__ = init
+    lines = []
+    rl.print = lambda *a, **k: lines.append(' '.join(str(x) for x in a))
+    try:
+        results = rl.QAgent.trial(estimator=agent.evaluate, num=6, game_init=game_init, storage='local', console='local')
+    finally:
+        gl.Game.__init__ = real_init
+        del rl.print
+    longest = max(len(g.moves) for g in results)
+    moves = np.full((len(results), longest), -2, np.int8)
+    tiles = np.zeros((len(results), longest, 2), np.uint8)
+    for i, g in enumerate(results):
+        assert len(g.moves) == len(g.tiles) == g.odometer
+        moves[i, :len(g.moves)] = g.moves
+        tiles[i, :len(g.tiles)] = [(t, p[0] * 4 + p[1]) for t, p in g.tiles]
+    save('trial_init.npz', n=TRIAL_N, seed=TRIAL_SEED + 1, lane0=TRIAL_LANE0, scale=2.0 ** -6, init_row=pick.astype(np.uint8), init_score=1500,
+         scores=np.array([g.score for g in results], np.int64), odometers=np.array([g.odometer for g in results], np.int64),
+         rows=np.stack([g.row for g in results]).astype(np.uint8),
+         starts=np.stack([np.asarray(g.starting_position) for g in results]).astype(np.uint8), moves=moves, tiles=tiles,
+         summary=np.array('\n'.join(lines)))
+    print(f'  trial(game_init): scores {[g.score for g in results]}, moves {[g.odometer for g in results]}')
+
+
 def built_pickles(gl, rl):
     """The reverse direction of f-2: objects pickled by the build, read by the reference."""
     g = np.load(os.path.join(HERE, 'features.npz'))
@@ -123,6 +168,7 @@ def built_pickles(gl, rl):
 if __name__ == '__main__':
     gl, rl = import_reference()
     trial(gl, rl)
+    trial_with_game_init(gl, rl)
     if os.path.exists(os.path.join(HERE, 'built_agent_local.pkl')):
         built_pickles(gl, rl)
     else:

@@ -121,6 +121,7 @@ def test_surface_game_and_agent(api, golden, tmp_path):
 
 def test_surface_trial_reproduces_the_reference_trial(api, golden, tmp_path):
     gs.test_trial_reproduces_the_reference_trial(api, golden, tmp_path)
+    gs.test_trial_with_game_init_reproduces_the_reference(api, golden)
 
 
 def test_surface_look_forward_and_reference_pickles(api, golden, tmp_path, monkeypatch):

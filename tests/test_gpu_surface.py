@@ -180,6 +180,41 @@ def test_trial_reproduces_the_reference_trial(api, golden, tmp_path):
     assert np.array_equal(chain[best.odometer][0], g['rows'][0]) and chain[best.odometer][1] == int(g['scores'][0])
 
 
+def test_trial_with_game_init_reproduces_the_reference(api, golden):
+    """QAgent.trial(game_init=...) (r_learning.py:363): every game is `game_init.copy()` — Game(score, row): a FRESH record from
+    a mid-game position (odometer 0, the trial's own moves and tiles only, starting_position = game_init.row).  The fixture is
+    the reference's own trial of 6 such games (tests/golden/make_golden3.py: trial_with_game_init); the prefix hung on game_init
+    there and here must not show up in the results."""
+    g = golden('trial_init.npz')
+    n = int(g['n'])
+    agent = api.QAgent(name='t', storage='local', console='local', n=n, with_weights=False)
+    sizes = formulas.feature_sizes(n)
+    flat = formulas.weights(n, scale=float(g['scale'])).astype(np.float32)
+    offs = np.concatenate([[0], np.cumsum(sizes)[:-1]])
+    agent.weights = [flat[o:o + s] for o, s in zip(offs, sizes)]
+    agent.trial_seed = (int(g['seed']), int(g['lane0']))
+    game_init = api.Game(score=int(g['init_score']), row=g['init_row'].astype(np.int32))
+    game_init.odometer, game_init.moves, game_init.tiles = 3, [0, 1, 2], [(1, (0, 0))] * 3
+    import builtins
+    real_print = builtins.print
+    builtins.print = lambda *a, **k: None
+    try:
+        results = api.QAgent.trial(estimator=agent.evaluate, num=len(g['scores']), game_init=game_init, storage='local', console='local')
+    finally:
+        builtins.print = real_print
+    assert [r.score for r in results] == g['scores'].tolist() and [r.odometer for r in results] == g['odometers'].tolist()
+    for i, r in enumerate(results):
+        k = int(g['odometers'][i])
+        assert np.array_equal(r.row, g['rows'][i]) and np.array_equal(r.starting_position, g['starts'][i])
+        assert np.array_equal(r.starting_position, g['init_row'])
+        assert r.moves == g['moves'][i, :k].tolist() and len(r.tiles) == k
+        assert [(t, p[0] * 4 + p[1]) for t, p in r.tiles] == [tuple(x) for x in g['tiles'][i, :k].tolist()]
+    best = results[0]                                           # a record that replays from game_init's position to its end
+    best.moves.append(-1)
+    chain = best.replay(verbose=False)
+    assert np.array_equal(chain[best.odometer][0], g['rows'][0])
+
+
 def test_trial_with_lookahead_plays_all_games_in_one_batch(api):
     """depth > 0 (game_logic.py:214-243 under trial_run): all games' trees go through lookahead.expectimax_values together.
     Every returned Game is a full record that replays to its final position; looking ahead does not play worse than greedy

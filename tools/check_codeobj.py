@@ -138,6 +138,77 @@ def check_inflight(ins):
     return sorted(set(bad))
 
 
+def check_lds_inflight(ins, cap):
+    """The other half of the asm contract: phase A reads the LDS copy into a register at or above `cap` (ds_read_b32), phase B
+    lets the cold lanes overwrite it with a masked global_load_dword.  An LDS word that returns AFTER the global one would
+    silently replace the table value, so on every path from such a ds_read_b32 to the first instruction that names its
+    destination (the global load into it, or the v_add_f32 that consumes it) there must be an `s_waitcnt lgkmcnt(0)`.
+    (lgkmcnt also counts scalar-memory loads, which return out of order: only a wait for 0 is accepted.)
+    Returns [(ds_read index, offending index)]."""
+    index_of = {a: i for i, (a, _, _) in enumerate(ins)}
+    parsed = []
+    for _, text, _ in ins:
+        op, _, rest = text.partition(' ')
+        parsed.append((op, rest, vregs(rest)))
+    bad = []
+    for li, (op, rest, _) in enumerate(parsed):
+        if not op.startswith('ds_read'):
+            continue
+        dest = vregs(rest.split(',')[0])
+        if not any(r >= cap for r in dest):
+            continue
+        seen, work = set(), [li + 1]
+        while work:
+            pc = work.pop()
+            while pc < len(ins):
+                if pc in seen:
+                    break
+                seen.add(pc)
+                op, rest, touched = parsed[pc]
+                if op.startswith('s_waitcnt'):
+                    if re.search(r'lgkmcnt\(0\)', rest):
+                        break                                   # the LDS word has landed on this path
+                    pc += 1
+                    continue
+                if dest & touched:
+                    bad.append((li, pc))
+                    break
+                if op == 's_endpgm':
+                    break
+                target = ins[pc][2]
+                if target is not None:
+                    if target in index_of:
+                        work.append(index_of[target])
+                    if op == 's_branch':
+                        break
+                pc += 1
+    return sorted(set(bad))
+
+
+def check_store_release(ins):
+    """mirror_stats (k_apply_orbits*): plain stores to pinned host memory, then a workgroup barrier, then the done-counter /
+    sequence word.  A workgroup-scope fence emits no vmcnt wait on gfx950, so the source asks for one explicitly; this makes
+    sure it is in the code object: walking back from every s_barrier, an `s_waitcnt vmcnt(0)` must come before any
+    global_store (in straight-line code; the search stops at a branch target boundary it cannot follow).
+    Returns the number of s_barrier instructions that have a global_store in front of them without such a wait."""
+    bad = 0
+    for i, (_, text, _) in enumerate(ins):
+        if not text.startswith('s_barrier'):
+            continue
+        j = i - 1
+        while j >= 0:
+            t = ins[j][1]
+            if t.startswith('s_waitcnt') and re.search(r'vmcnt\(0\)', t):
+                break
+            if t.startswith(('global_store', 'flat_store')):
+                bad += 1
+                break
+            if t.startswith(('s_branch', 's_cbranch', 's_endpgm', 's_barrier')):
+                break
+            j -= 1
+    return bad
+
+
 def main():
     so = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, '2048_amd', 'lib2048_hip.so')
     failures = []
@@ -169,8 +240,15 @@ def main():
             loads = sum(1 for _, x, _ in ins if x.startswith('global_load_dword '))
             fences = sum(1 for _, x, _ in ins if x.startswith('s_waitcnt vmcnt(0)'))
             bad = check_inflight(ins)
+            bad_lds = check_lds_inflight(ins, cap[kind])
+            lds_reads = sum(1 for _, x, _ in ins if x.startswith('ds_read_b32 ') and any(r >= cap[kind] for r in vregs(x.split(',')[0])))
             print(f'[codeobj] {name}: {d["vgpr_count"]} VGPRs, scratch {d["private_segment_fixed_size"]} B, LDS {d["group_segment_fixed_size"]} B, '
-                  f'{len(ins)} instructions, {loads} global_load_dword, {fences} full vmcnt fences, {len(bad)} in-flight register touches')
+                  f'{len(ins)} instructions, {loads} global_load_dword, {fences} full vmcnt fences, {len(bad)} in-flight register touches, '
+                  f'{lds_reads} ds_read_b32 above the cap, {len(bad_lds)} touched before lgkmcnt(0)')
+            if lds_reads < guarded[kind]:
+                failures.append(f'{name}: only {lds_reads} ds_read_b32 into registers >= v{cap[kind]} (expected >= {guarded[kind]})')
+            for li, oi in bad_lds[:5]:
+                failures.append(f'{name}: "{ins[oi][1]}" names the destination of "{ins[li][1]}" on a path without s_waitcnt lgkmcnt(0) in between')
             # the registers above the cap belong to the asm statements: LDS read into, masked global load into, v_add_f32 from
             foreign = []
             for _, text, _ in ins:
@@ -189,6 +267,15 @@ def main():
                 failures.append(f'{name}: only {loads} global_load_dword (expected >= {guarded[kind]}): is the LDS + masked-load path still there?')
             for li, oi in bad[:5]:
                 failures.append(f'{name}: "{ins[oi][1]}" names the destination of "{ins[li][1]}" (issued {oi - li} instructions earlier) on a path without a covering s_waitcnt')
+        for k in sorted(notes):
+            if 'k_apply_orbits' not in k:
+                continue
+            ins = disassemble(co, k)
+            unguarded = check_store_release(ins)
+            short = 'k_apply_orbits_mean' if 'k_apply_orbits_mean' in k else 'k_apply_orbits'
+            print(f'[codeobj] {short}: {sum(1 for _, x, _ in ins if x.startswith("s_barrier"))} s_barrier, {unguarded} with a store in front and no vmcnt(0) wait')
+            if unguarded:
+                failures.append(f'{short}: a global store reaches an s_barrier without s_waitcnt vmcnt(0) (mirror_stats publishes host-visible data behind that barrier)')
     if failures:
         print('\n'.join('[codeobj] FAIL: ' + f for f in failures))
         return 1
