@@ -179,17 +179,17 @@ def test_qagent_train_run_two_ranks_on_the_cpu_backend(tmp_path):
     assert 'training session started' in outs[0][0] and 'on each of 2 GPUs' in outs[0][0] and 'training session started' not in outs[1][0]
 
 
-def _bench_cpu(*extra, timeout=300):
+def _bench_cpu(*extra, timeout=300, gpus=2, n=4, batch=2048, threads=2):
     import json
     import subprocess
     import sys
     import time
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, G2048_BACKEND='cpu', G2048_CPU_THREADS='2')
+    env = dict(os.environ, G2048_BACKEND='cpu', G2048_CPU_THREADS=str(threads))
     for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
         env.pop(k, None)
     t0 = time.monotonic()
-    res = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--batch', '2048', '--n-tuple', '4', '--steps', '6',
+    res = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', str(gpus), '--backend', 'gloo', '--batch', str(batch), '--n-tuple', str(n), '--steps', '6',
                           '--warmup', '2', '--condition', '4', '--epoch', '3', '--repeats', '1', '--no-cpu-baseline', '--trained-steps', '0', *extra],
                          capture_output=True, text=True, timeout=timeout, env=env)
     line = json.loads(res.stdout.strip().splitlines()[-1]) if res.returncode == 0 and res.stdout.strip() else None
@@ -214,3 +214,33 @@ def test_bench_rank_killed_mid_run_on_the_cpu_backend():
     res, line, dt = _bench_cpu('--comm', 'torch', '--fault-inject', 'exit@1:run')
     assert res.returncode != 0 and line is None and dt < 120
     assert 'rank 1 exited with code 3' in res.stderr and res.stdout.strip() == ''
+
+
+# ---- BASELINE config 5 (8 x MI355X, 6-tuple table, per-epoch all-reduce of the weight deltas): its first run on hardware is the
+# driver's, so the exact command is rehearsed here with eight real engines on the CPU backend — everything but RCCL itself
+
+def test_bench_config5_eight_ranks_n6_rehearsal():
+    """`bench.py --gpus 8 --n-tuple 6` through the self-launcher with eight ranks (gloo as transport, reduced --batch): the
+    eight-rank rendezvous, lane0 = rank x B up to rank 7, the 382.65 MB exchange through run_epochs, the native path's set-up
+    protocol failing on EVERY rank together, the line's comm block with the evidence of what ran."""
+    res, line, _ = _bench_cpu('--comm', 'native', gpus=8, n=6, batch=256, threads=1, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert line['n_gpus'] == 8 and line['steps'] == 6 and line['scaling'] == 'weak' and line['value'] > 0
+    assert 'BASELINE config 5' in line['config']['workload'] and line['config']['n_tuple'] == 6
+    comm = line['comm']
+    assert comm['nranks_seen'] == 8 and comm['nranks_expected'] == 8 and comm['payload_bytes'] == 95662848 * 4
+    assert comm['lane0_per_rank'] == [r * 256 for r in range(8)]            # eight distinct shards, rank 7 included
+    assert comm['replicas_identical'] and len({tuple(c) for c in comm['table_checksums_per_rank']}) == 1
+    assert comm['exchanges_per_timed_region'] == 2 and comm['allreduce_plus_apply_ms'] > 0
+    assert res.stderr.count('native RCCL path unavailable') == 8            # all eight fell back together
+
+
+def test_bench_eight_ranks_rank_killed_and_deadline():
+    """The launcher's failure handling at N = 8: rank 5 dies between two exchanges while seven survivors wait in the all-reduce
+    (the parent ends the job, names the rank, prints no line); two ranks hang at start-up and --deadline ends the run."""
+    res, line, dt = _bench_cpu('--comm', 'torch', '--fault-inject', 'exit@5:run', gpus=8, batch=512, threads=1)
+    assert res.returncode != 0 and line is None and dt < 150
+    assert 'rank 5 exited with code 3' in res.stderr and res.stdout.strip() == ''
+    res, line, dt = _bench_cpu('--comm', 'torch', '--fault-inject', 'hang@3:init,hang@6:init', '--deadline', '25', gpus=8, batch=512, threads=1)
+    assert res.returncode != 0 and line is None and 20 < dt < 120
+    assert '--deadline 25 s passed' in res.stderr and res.stdout.strip() == ''
