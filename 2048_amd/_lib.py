@@ -74,6 +74,8 @@ SIGNATURES = {
     'g2048_spawn_injected': (c_int, [_P, _P, _P]),
     'g2048_boards_move_all': (c_int, [_P, _P, c_int64, _P, _P, _P]),
     'g2048_boards_evaluate': (c_int, [_P, _P, c_int64, _P]),
+    'g2048_boards_look_forward': (c_int, [_P, _P, c_int64, c_int, c_int, c_int, _P, _P]),
+    'g2048_lookahead_steps': (c_int, [_P, c_int, c_int, c_int, c_int, c_uint32]),
     'g2048_step_random': (c_int, [_P, c_uint32]),
     'g2048_features': (c_int, [_P, _P]),
     'g2048_weights_set': (c_int, [_P, _P, c_int64]),
@@ -130,7 +132,7 @@ def load(backend=None):
             fn = getattr(lib, name)          # AttributeError here = header and library disagree
             fn.restype = res
             fn.argtypes = args
-        if lib.g2048_abi_version() != 2:
+        if lib.g2048_abi_version() != 3:
             raise G2048Error(ERR_STATE, 'ABI version mismatch')
         _libs[backend] = lib
     return _libs[backend]

@@ -598,8 +598,8 @@ class QAgent:
         owner = getattr(estimator, '__self__', None)
         on_device = (isinstance(owner, QAgent) and getattr(estimator, '__name__', '') == 'evaluate' and not verbose and not stopper)
         if on_device:
-            # all `num` games at once: depth 0 entirely on the device (with its game records), depth > 0 with every game's
-            # look-ahead tree in the same level-by-level batches (2048_amd/lookahead.py)
+            # all `num` games at once, entirely on the device with its game records: depth 0 greedy, depth > 0 with every game's
+            # look-ahead tree expanded and reduced in HBM (csrc/lookahead.hip)
             results = owner._trial_batched(num, game_init, depth=depth, width=width, since_empty=since_empty, limit_tile=limit_tile)
             for i, game in enumerate(results):
                 display(f'game {i}, result {game.score}, moves {game.odometer}, achieved {1 << np.max(game.row)}')
@@ -648,25 +648,29 @@ class QAgent:
     TRIAL_LOG_BYTES = 1 << 31         # device memory the game records of one trial may take
 
     def _trial_batched(self, num, game_init=None, depth=0, width=1, since_empty=6, limit_tile=0):
-        """`num` greedy games at once (r_learning.py:362-376 runs them one after the other), each a full reference
-        `Game`: row, score, odometer, moves, tiles, starting_position — what `results[0].save_game` / show.py's replay need
-        (game_logic.py:163-167 appends every move, :118-121 every tile).
-        depth 0: on the device, alpha = 0 (no records, no learning), the lanes' game logs switched on for all of them;
-        `self.trial_seed = (seed, lane0)` fixes the lanes' RNG streams (default: away from the training lanes).
-        depth > 0 or limit_tile: `_trial_lookahead`."""
-        if depth > 0 or limit_tile:
-            return self._trial_lookahead(num, game_init, depth, width, since_empty, limit_tile)
+        """`num` games at once (r_learning.py:362-376 runs them one after the other), each a full reference `Game`: row, score,
+        odometer, moves, tiles, starting_position — what `results[0].save_game` / show.py's replay need (game_logic.py:163-167
+        appends every move, :118-121 every tile).  Everything happens on the device, the lanes' game logs switched on for all of
+        them; `self.trial_seed = (seed, lane0)` fixes the lanes' RNG streams (default: away from the training lanes).
+        depth 0, no tile limit: greedy TD steps with alpha = 0 (no records, no learning).
+        depth > 0 or limit_tile: g2048_lookahead_steps — Game.trial_run with look-ahead (game_logic.py:150-183, 214-243) for all
+        games in lock step, every game's expectimax tree expanded, evaluated and reduced in HBM (csrc/lookahead.hip); the chance
+        nodes of a move are keyed by the lane's RNG state (rng.lookahead_draws)."""
         seed, lane0 = getattr(self, 'trial_seed', (self.seed + 77, 1 << 41))
         eng = Engine(num, seed=seed, lane0=lane0, share_table_of=self.engine)
         eng.set_auto_reset(False)
         if game_init is not None:
             eng.set_boards(np.repeat(np.asarray(game_init.row, np.uint8)[None], num, axis=0))
             eng.set_scores(np.full(num, game_init.score, np.int32))
-        capacity = int(min(self.LOG_CAPACITY, max(2048, self.TRIAL_LOG_BYTES // (4 * num))))
+        capacity = int(min(self.LOG_CAPACITY if depth == 0 else 4 * self.LOG_CAPACITY, max(2048, self.TRIAL_LOG_BYTES // (4 * num))))
         eng.log_enable(num, capacity)
         eng.stats_reset()
+        searching = depth > 0 or bool(limit_tile)
         while eng.stats()['episodes'] < num:                   # every lane ends exactly once (auto-reset is off)
-            eng.td_steps(0.0, 256)
+            if searching:
+                eng.lookahead_steps(depth, width, since_empty, limit_tile, 64)
+            else:
+                eng.td_steps(0.0, 256)
         meta = eng.log_meta()
         games = []
         for lane in range(num):
@@ -682,72 +686,6 @@ class QAgent:
             # which is what the device's record holds, its start being the board set above)
             games.append(game)
         eng.close()
-        return games
-
-    def _trial_lookahead(self, num, game_init, depth, width, since_empty, limit_tile):
-        """Game.trial_run with look-ahead (game_logic.py:150-183, 214-243) for `num` games in lock step: one
-        g2048_boards_move_all for the candidates of all games, ONE expectimax tree batch for all of them
-        (lookahead.expectimax_values: the children of every node of every game per level), first maximum per game, then
-        the new tiles.  New tiles and sampled chance nodes come from a NumPy generator (the reference draws both from
-        Python's `random`), seeded by `self.trial_seed`."""
-        from . import lookahead
-        eng = self.engine
-        seed = getattr(self, 'trial_seed', (self.seed + 77, 1 << 41))[0]
-        rng = np.random.default_rng(seed)
-        sampler = lookahead.random_sampler(rng)
-
-        def spawn(b):
-            """One new tile on every board of b [M,16] (game_logic.py:112-121); returns (tile, cell)."""
-            keys = rng.random(b.shape)
-            keys[b != 0] = 2.0
-            cell = np.argmin(keys, axis=1)                     # a uniformly chosen empty cell
-            tile = np.where(rng.integers(0, 10, len(b)) == 0, 2, 1).astype(np.uint8)
-            b[np.arange(len(b)), cell] = tile
-            return tile, cell
-
-        boards = np.zeros((num, 16), np.uint8)
-        scores = np.zeros(num, np.int64)
-        if game_init is not None:
-            boards[:] = np.asarray(game_init.row, np.uint8).reshape(16)
-            scores[:] = game_init.score
-        else:
-            spawn(boards)
-            spawn(boards)
-        start = boards.copy()
-        moves, tiles = [[] for _ in range(num)], [[] for _ in range(num)]
-        live = np.arange(num)
-        while len(live):
-            after, reward, changed = eng.boards_move_all(boards[live])
-            go = changed != 0                                  # game over <=> no direction changes the board
-            if limit_tile:
-                go &= boards[live].max(axis=1) < limit_tile
-            live, after, reward, changed = live[go], after[go], reward[go], changed[go]
-            if not len(live):
-                break
-            gi, di = np.nonzero((changed[:, None] >> np.arange(4)[None, :]) & 1)
-            vals = lookahead.expectimax_values(eng, after[gi, di], depth, width, since_empty, sampler)
-            best = np.full(len(live), -np.inf)
-            np.maximum.at(best, gi, vals)
-            first = np.full(len(live), 4)
-            hit = vals >= best[gi]
-            np.minimum.at(first, gi[hit], di[hit])             # strict '>' from -inf keeps the first maximum
-            fallback = np.full(len(live), 4)
-            np.minimum.at(fallback, gi, di)                    # (all values NaN: still a legal move)
-            first = np.where(first < 4, first, fallback)
-            idx = np.arange(len(live))
-            chosen = after[idx, first].reshape(-1, 16).copy()
-            tile, cell = spawn(chosen)
-            boards[live] = chosen
-            scores[live] += reward[idx, first]
-            for g, d, t, c in zip(live.tolist(), first.tolist(), tile.tolist(), cell.tolist()):
-                moves[g].append(d)
-                tiles[g].append((t, (c >> 2, c & 3)))
-        games = []
-        for g in range(num):
-            game = Game(score=int(scores[g]), row=boards[g].reshape(4, 4).astype(np.int32))
-            game.starting_position = start[g].reshape(4, 4).astype(np.int32)
-            game.moves, game.tiles, game.odometer = moves[g], tiles[g], len(moves[g])
-            games.append(game)             # (game_init: a fresh record from game_init.row, as game_init.copy() is — see _trial_batched)
         return games
 
 

@@ -517,6 +517,151 @@ void update_impl(g2048_ctx* c, const uint8_t* states, const float* dw, int64_t c
 
 }  // namespace
 
+// ---- look-ahead: Game.look_forward (game_logic.py:214-243) as the scalar recursion it is, with the chance nodes of the
+// device's spec (2048_amd/rng.py: lookahead_draws — a function of the node's board and a salt) and its fp32 arithmetic
+namespace {
+struct Salt {
+    uint64_t s0, s1;
+};
+Rng la_rng(const Board& b, const Salt& salt) {
+    const uint64_t lo = (uint64_t)b.r[0] | (uint64_t)b.r[1] << 32, hi = (uint64_t)b.r[2] | (uint64_t)b.r[3] << 32;
+    uint64_t x = salt.s0 ^ lo;
+    const uint64_t a = splitmix64(x);
+    x = (x ^ hi) + salt.s1;
+    Rng g;
+    g.s0 = splitmix64(x);
+    x ^= a;
+    g.s1 = splitmix64(x);
+    if ((g.s0 | g.s1) == 0) g.s0 = 1;
+    return g;
+}
+template <int N>
+float look_forward(const float* w, const Board& b, int depth, int width, int since_empty, const Salt& salt) {
+    if (depth == 0) return value_of<N>(w, b);
+    uint32_t free_cells = empty_bits(b);
+    const uint32_t ne = popcount32(free_cells);
+    if ((int)ne >= since_empty) return value_of<N>(w, b);
+    const uint32_t k = ne < (uint32_t)width ? ne : (uint32_t)width;
+    if (k == 0) return NAN;                     // a full board: the reference divides by zero (:242)
+    Rng g = la_rng(b, salt);
+    float acc = 0.0f;
+    for (uint32_t j = 0; j < k; ++j) {
+        uint32_t r10, kk;
+        spawn_draw(next_u64(g), popcount32(free_cells), r10, kk);
+        Board child = b;
+        place_tile(child, r10, kk, free_cells);
+        free_cells &= ~(1u << kth_set_bit(free_cells, kk));
+        const Moves4 mv = all_moves(child);
+        float best = -INFINITY;
+        bool any = false;
+        for (int d = 0; d < 4; ++d)
+            if (mv.m[d].changed) {
+                any = true;
+                const float v = look_forward<N>(w, mv.m[d].after, depth - 1, width, since_empty, salt);
+                if (v > best) best = v;
+            }
+        const float wj = any ? best : -100.0f;
+        acc += (0.0f > wj) ? 0.0f : wj;
+    }
+    return acc / (float)k;
+}
+int la_args(g2048_ctx* c, int depth, int width, int since_empty, int limit_tile) {
+    NEED(c, depth >= 0 && depth <= 6, "look-ahead depth out of range (0 .. 6)");
+    NEED(c, width >= 1 && width <= 16, "look-ahead width out of range (1 .. 16)");
+    NEED(c, since_empty >= 0 && limit_tile >= 0, "negative since_empty / limit_tile");
+    double leaves = 1;
+    for (int l = 0; l < depth; ++l) leaves *= 4.0 * width;
+    NEED(c, leaves <= 4194304.0, "look-ahead tree too large: (4 width)^depth must stay below 2^22 nodes per position");
+    return G2048_OK;
+}
+}  // namespace
+
+namespace {
+template <int N>
+void lookahead_step(g2048_ctx* c, int depth, int width, int since_empty, uint32_t limit_tile) {
+    const float* w = c->table->w.data();
+    const int nthreads = c->threads;
+    (void)nthreads;
+    std::vector<g2048_stats> part((size_t)std::max(1, nthreads));
+    GameLogHost& lg = c->log;
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 1)
+    for (long long ii = 0; ii < (long long)c->B; ++ii) {
+        const uint32_t i = (uint32_t)ii;
+#ifdef _OPENMP
+        g2048_stats& st = part[(size_t)omp_get_thread_num()];
+#else
+        g2048_stats& st = part[0];
+#endif
+        uint8_t fl = c->flags[i];
+        if (fl & DONE) {
+            c->last_move[i] = 0;
+            continue;
+        }
+        Board b = c->boards[i];
+        Rng g = c->rng[i];
+        int32_t score = c->scores[i];
+        const Salt salt{g.s0, g.s1};
+        int action = -1, first_valid = -1;
+        float best = -INFINITY;
+        const Moves4 mv = all_moves(b);
+        if (!(limit_tile && max_tile(b) >= limit_tile))
+            for (int d = 0; d < 4; ++d)
+                if (mv.m[d].changed) {
+                    if (first_valid < 0) first_valid = d;
+                    const float v = look_forward<N>(w, mv.m[d].after, depth, width, since_empty, salt);
+                    if (v > best) {
+                        best = v;
+                        action = d;
+                    }
+                }
+        if (action < 0) action = first_valid;
+        uint32_t lm = 0;
+        bool moved = false, over, overflow = false;
+        if (action >= 0) {
+            const Moved& m = mv.m[action];
+            score += (int32_t)merged_score(m.ma, m.mb);
+            b = m.after;
+            moved = true;
+            st.moves += 1;
+            st.valid_dirs += popcount32(changed_mask(mv));
+            lm = (uint32_t)action | 4u;
+            if (spawn(b, g)) {
+                for (int r = 0; r < 4; ++r) {
+                    const uint32_t d = b.r[r] ^ m.after.r[r];
+                    if (d) {
+                        const uint32_t col = (uint32_t)__builtin_ctz(d) >> 3;
+                        lm |= ((uint32_t)(4 * r) + col) << 4 | ((d >> (8 * col)) & 3u) << 8 | 1u << 10;
+                    }
+                }
+            }
+            overflow = max_tile(b) >= 16u;
+            over = game_over(b) || overflow || (limit_tile && max_tile(b) >= limit_tile);
+        } else {
+            over = true;
+        }
+        const int32_t final_score = score;
+        const Board final_board = b;
+        if (over) {
+            lm |= 1u << 11;
+            count_finished(st, b, score, overflow);
+            if (c->auto_reset) {
+                b = new_game(g);
+                score = 0;
+            } else {
+                fl |= DONE;
+            }
+        }
+        if (i < lg.lanes) log_step(lg, i, lm, moved, over, final_score, over && c->auto_reset, b, final_board);
+        c->boards[i] = b;
+        c->rng[i] = g;
+        c->scores[i] = score;
+        c->flags[i] = fl;
+        c->last_move[i] = (uint16_t)lm;
+    }
+    for (const auto& s : part) merge_stats(c->stats, s);
+}
+}  // namespace
+
 extern "C" {
 
 int g2048_abi_version(void) { return G2048_ABI_VERSION; }
@@ -881,6 +1026,36 @@ int g2048_boards_evaluate(g2048_ctx* c, const uint8_t* boards, int64_t count, fl
     if (!c || !boards || !value || count < 0) return c ? fail(c, G2048_ERR_ARG, "null buffer / bad count") : G2048_ERR_ARG;
     NEED_TABLE(c);
     BY_N(c, evaluate_impl<N>(c, nullptr, boards, count, value));
+    return G2048_OK;
+}
+
+int g2048_boards_look_forward(g2048_ctx* c, const uint8_t* boards, int64_t count, int depth, int width, int since_empty, const uint64_t* salt, float* value) {
+    if (!c || !boards || !value || count < 0) return c ? fail(c, G2048_ERR_ARG, "null buffer / bad count") : G2048_ERR_ARG;
+    NEED_TABLE(c);
+    if (int rc = la_args(c, depth, width, since_empty, 0)) return rc;
+    const float* w = c->table->w.data();
+    const int nthreads = c->threads;
+    (void)nthreads;
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 1)
+    for (long long i = 0; i < (long long)count; ++i) {
+        const Salt s = salt ? Salt{salt[2 * i], salt[2 * i + 1]} : Salt{0, 0};
+        const Board b = load_board(boards + 16 * i);
+        switch (c->n) {
+            case 2: value[i] = look_forward<2>(w, b, depth, width, since_empty, s); break;
+            case 3: value[i] = look_forward<3>(w, b, depth, width, since_empty, s); break;
+            case 4: value[i] = look_forward<4>(w, b, depth, width, since_empty, s); break;
+            case 5: value[i] = look_forward<5>(w, b, depth, width, since_empty, s); break;
+            default: value[i] = look_forward<6>(w, b, depth, width, since_empty, s); break;
+        }
+    }
+    return G2048_OK;
+}
+
+int g2048_lookahead_steps(g2048_ctx* c, int depth, int width, int since_empty, int limit_tile, uint32_t nsteps) {
+    if (!c) return G2048_ERR_ARG;
+    NEED_TABLE(c);
+    if (int rc = la_args(c, depth, width, since_empty, limit_tile)) return rc;
+    for (uint32_t s = 0; s < nsteps; ++s) BY_N(c, lookahead_step<N>(c, depth, width, since_empty, (uint32_t)std::min(limit_tile, 255)));
     return G2048_OK;
 }
 

@@ -157,6 +157,19 @@ class Engine:
         self._c(self.lib.g2048_boards_evaluate(self.ctx, _buf(b), len(b), _buf(v)))
         return v
 
+    def boards_look_forward(self, boards, depth, width, since_empty, salt=None):
+        """Stateless: V_depth(board) of Game.look_forward (game_logic.py:214-243) for any number of boards, every tree expanded and
+        reduced on the device; salt uint64[n, 2] keys the chance nodes (rng.lookahead_draws), None = zeros."""
+        b = np.ascontiguousarray(np.asarray(boards).reshape(-1, 16), np.uint8)
+        v = np.empty(len(b), np.float32)
+        s = None if salt is None else np.ascontiguousarray(salt, np.uint64).reshape(len(b), 2)
+        self._c(self.lib.g2048_boards_look_forward(self.ctx, _buf(b), len(b), int(depth), int(width), int(since_empty), _buf(s) if s is not None else None, _buf(v)))
+        return v
+
+    def lookahead_steps(self, depth, width, since_empty, limit_tile=0, nsteps=1):
+        """nsteps moves of Game.trial_run with look-ahead for every live lane (choice, move, new tile, end test), on the device."""
+        self._c(self.lib.g2048_lookahead_steps(self.ctx, int(depth), int(width), int(since_empty), int(limit_tile), int(nsteps)))
+
     def step_random(self, nsteps):
         self._c(self.lib.g2048_step_random(self.ctx, int(nsteps)))
 

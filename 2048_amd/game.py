@@ -10,7 +10,7 @@ import threading
 from .start import *  # noqa: F401,F403  (the reference's modules star-import start.py the same way)
 from .start import GAME_PANE, Thread, np, pickle, random
 
-from . import _lib, lookahead
+from . import _lib
 from .engine import Engine
 
 
@@ -59,13 +59,6 @@ class _Device:
 
 
 _DEVICE = _Device()
-_SAMPLER = []
-
-
-def _sampler():
-    if not _SAMPLER:
-        _SAMPLER.append(lookahead.random_sampler())
-    return _SAMPLER[0]
 
 
 def create_table():
@@ -208,13 +201,15 @@ class Game:
         best_value = -np.inf
         engine = getattr(getattr(estimator, '__self__', None), 'engine', None)
         if depth > 0 and engine is not None and getattr(estimator, '__name__', '') == 'evaluate':
-            # the estimator is a device agent: the whole look-ahead tree of the four candidates is evaluated level by
-            # level in batches (2048_amd/lookahead.py) instead of node by node
+            # the estimator is a device agent: the look-ahead trees of the four candidates are expanded, evaluated and reduced
+            # on the device (g2048_boards_look_forward, csrc/lookahead.hip) instead of node by node; their chance nodes are
+            # keyed by a fresh salt from `random` (the reference draws them from `random` too)
             after, reward, changed = _DEVICE.move_all(self.row)
             dirs = [d for d in range(4) if (changed >> d) & 1]
             if not dirs:
                 return best
-            values = lookahead.expectimax_values(engine, after[dirs].astype(np.uint8), depth, width, since_empty, _sampler())
+            salt = np.array([[random.getrandbits(64), random.getrandbits(64)]] * len(dirs), np.uint64)
+            values = engine.boards_look_forward(after[dirs].astype(np.uint8), depth, width, since_empty, salt)
             Game.counter += 4
             for d, value in zip(dirs, values):
                 if value > best_value:

@@ -1,7 +1,10 @@
-"""Batched sampled expectimax — `Game.look_forward` (game2048/game_logic.py:214-243) for many positions at once.
+"""Batched sampled expectimax with a CALLER-SUPPLIED sampler — `Game.look_forward` (game2048/game_logic.py:214-243) for many
+positions at once.
 
-The reference walks the tree one node at a time (README.md:145: "1 second per move" at depth 3, width 4).  Here a whole
-level of the tree is one batch: the children of every node are built on the host (placing a tile is one byte), all
+The product path is on the device: `Engine.boards_look_forward` / `Engine.lookahead_steps` (csrc/lookahead.hip) expand, evaluate
+and reduce every tree in HBM and draw the chance nodes from the device's own spec (rng.lookahead_draws); `Game._find_best_move`
+and `QAgent.trial(depth > 0)` use those.  This module is the form for a sampler the device cannot know (a test that injects
+draws keyed some other way): a whole level of the tree is one batch, the children of every node are built on the host, all
 their moves come from one `g2048_boards_move_all` call and all leaf values from one `g2048_boards_evaluate` call.
 
     V_0(s)            = estimator(s)

@@ -71,6 +71,47 @@ class LaneRng:
         return u
 
 
+# ---------------------------------------------------------------- chance nodes of the look-ahead (g2048_boards_look_forward)
+
+def lookahead_rng(board16, salt=(0, 0)):
+    """The stream the look-ahead samples a chance node from (Game.look_forward, game_logic.py:221-225: `random.sample` of the
+    empty cells, then `randrange(10)` per tile).  The reference draws depth-first from one global Mersenne Twister; the device
+    walks all trees level by level, so the draws are defined as a FUNCTION of the node — a xoroshiro128++ stream keyed by the
+    node's board and a salt (for a game: the lane's RNG state when the move is chosen, so that the same position gets other
+    samples in another game or at another move) — and are the same in whatever order the nodes are visited:
+
+        lo, hi = the 16 board bytes as two little-endian u64
+        x = salt0 ^ lo;            a  = splitmix64(x)        (x advances by the golden constant, as in seed_lane)
+        x = (x ^ hi) + salt1;      s0 = splitmix64(x)
+        x = x ^ a;                 s1 = splitmix64(x)
+    """
+    b = bytes(bytearray(int(v) for v in board16))
+    assert len(b) == 16
+    lo, hi = int.from_bytes(b[:8], 'little'), int.from_bytes(b[8:], 'little')
+    x = (salt[0] ^ lo) & MASK64
+    x, a = splitmix64(x)
+    x = ((x ^ hi) + salt[1]) & MASK64
+    x, s0 = splitmix64(x)
+    x ^= a
+    x, s1 = splitmix64(x)
+    if (s0 | s1) == 0:
+        s0 = 1
+    return LaneRng(0, state=(s0, s1))
+
+
+def lookahead_draws(board16, k, salt=(0, 0)):
+    """[(cell, tile)] x k: the sampled chance nodes of `board16` — k distinct empty cells (flat row-major index) without
+    replacement, one draw each: (r10, j) = spawn_draw(u, cells still free) picks the j-th free cell in row-major order and the
+    tile (2 iff r10 == 0), exactly as a spawn does."""
+    g = lookahead_rng(board16, salt)
+    free = [i for i, v in enumerate(board16) if int(v) == 0]
+    out = []
+    for _ in range(k):
+        r10, j = spawn_draw(g.next(), len(free))
+        out.append((free.pop(j), 2 if r10 == 0 else 1))
+    return out
+
+
 # ---------------------------------------------------------------- numpy twin (vectorised)
 
 def seed_lanes(seed, lane0, count):

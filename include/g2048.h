@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define G2048_ABI_VERSION 2
+#define G2048_ABI_VERSION 3
 
 enum {
     G2048_OK = 0,
@@ -127,6 +127,23 @@ int g2048_weights_init(g2048_ctx* ctx, uint64_t seed, float scale);       /* U[0
 int g2048_evaluate(g2048_ctx* ctx, float* value /* [B] */);               /* QAgent.evaluate, r_learning.py:202-203 */
 /* the same for `count` caller-supplied boards (the lanes are not touched) */
 int g2048_boards_evaluate(g2048_ctx* ctx, const uint8_t* boards /* [count][16] */, int64_t count, float* value /* [count] */);
+/* Game.look_forward (game_logic.py:214-243) — the reference's sampled expectimax — for `count` caller-supplied positions (the lanes
+ * are not touched): value[i] = V_depth(boards[i]) with
+ *     V_0(s) = evaluate(s);   V_d(s) = evaluate(s) if empty(s) >= since_empty, else the mean over min(width, empty(s)) sampled new
+ *     tiles t of max(0, W(s + t));   W(c) = -100 if c is game over, else the max over the directions that change c of V_{d-1}.
+ * All trees are expanded, evaluated and reduced level by level on the device (csrc/lookahead.hip).  The chance nodes of a position
+ * are a function of its board and salt[i] (two words; NULL = zeros): the xoroshiro128++ stream of 2048_amd/rng.py
+ * `lookahead_draws` — distinct empty cells without replacement, tile 2 with probability 1/10 — so the same draws can be fed to the
+ * reference's recursion (tests/golden/make_golden4.py).  A full board (no sample possible) yields NaN where the reference divides
+ * by zero.  depth 0 .. 6, width 1 .. 16, (4 width)^depth <= 2^22. */
+int g2048_boards_look_forward(g2048_ctx* ctx, const uint8_t* boards /* [count][16] */, int64_t count, int depth, int width, int since_empty,
+                              const uint64_t* salt /* [count][2] or NULL */, float* value /* [count] */);
+/* nsteps x the body of Game.trial_run (game_logic.py:170-183) with look-ahead for every live lane: Game._find_best_move (:150-161:
+ * first maximum of look_forward over the directions that change the board; the salt of a lane's chance nodes is its RNG state at
+ * that move, no draw is consumed), Game._move_on (:163-167: the move, the new tile from the lane's stream), then the loop's tests:
+ * a lane ends when its game is over or a tile >= 2^limit_tile is on the board (limit_tile 0: never) — counted in the statistics and
+ * recorded in the game logs like a TD step's.  Nothing is learned.  depth 0 is the greedy choice.  ASYNCHRONOUS. */
+int g2048_lookahead_steps(g2048_ctx* ctx, int depth, int width, int since_empty, int limit_tile, uint32_t nsteps);
 /* greedy afterstate choice (r_learning.py:229-237, game_logic.py:150-161 at depth 0): first maximum over the
  * directions that change the board; action 255 / value 0 when none does.  values4 ([B][4], may be NULL) gets
  * V(afterstate d) or -inf.  value and action may both be NULL: the kernel runs and nothing is copied back. */

@@ -45,7 +45,7 @@ def test_cpu_library_exports_the_whole_abi():
     lib = ctypes.CDLL(_lib.CPU_LIB_PATH)
     for name in _lib.SIGNATURES:
         assert hasattr(lib, name), f'{name} is declared in include/g2048.h but not exported by lib2048_cpu.so'
-    assert _lib.load('cpu').g2048_abi_version() == 2
+    assert _lib.load('cpu').g2048_abi_version() == 3
     eng = pkg.Engine(4, n=2)
     assert eng.backend == 'cpu' and eng.lib is _lib.load('cpu')
     eng.close()
@@ -126,6 +126,8 @@ def test_surface_trial_reproduces_the_reference_trial(api, golden, tmp_path):
 
 def test_surface_look_forward_and_reference_pickles(api, golden, tmp_path, monkeypatch):
     gs.test_look_forward_matches_reference_fixture(api, golden)
+    gs.test_device_look_forward_matches_the_reference(golden)
+    gs.test_trial_with_lookahead_reproduces_the_reference_trial(api, golden)
     gs.test_reference_written_pickles_load(api, golden, tmp_path, monkeypatch)
     gs.test_device_game_records(api)
 

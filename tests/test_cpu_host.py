@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
         assert name in _lib.SIGNATURES, f'{name} has no ctypes signature in 2048_amd/_lib.py'
     assert set(_lib.SIGNATURES) <= set(names)
     lib = pkg.load_library()
-    assert lib.g2048_abi_version() == 2
+    assert lib.g2048_abi_version() == 3
     assert [lib.g2048_num_feat(n) for n in (2, 3, 4, 5, 6)] == [24, 52, 17, 21, 33]
     assert lib.g2048_num_feat(7) == -1
     assert [lib.g2048_table_slots(n) for n in (2, 3, 4, 5, 6)] == [6144, 212992, 1114112, 5308416, 95662848]

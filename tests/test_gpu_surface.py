@@ -215,6 +215,72 @@ def test_trial_with_game_init_reproduces_the_reference(api, golden):
     assert np.array_equal(chain[best.odometer][0], g['rows'][0])
 
 
+def test_device_look_forward_matches_the_reference(golden):
+    """g2048_boards_look_forward (csrc/lookahead.hip: every tree expanded, evaluated and reduced level by level in HBM) against
+    the REFERENCE's own recursion, Game.look_forward / Game._find_best_move (game_logic.py:150-161, 214-243), run by
+    tests/golden/make_golden4.py with the chance nodes of the device's sampling spec (rng.lookahead_draws) fed to it: values
+    within fp32 rounding of the float64 recursion (dyadic tables: the leaves are exact, the means divide by k), best moves equal."""
+    import importlib
+    pkg = importlib.import_module('2048_amd')
+    g = golden('lookahead_dev.npz')
+    boards, configs, salts = g['boards'], g['configs'], g['salts']
+    for n in (3, 5):
+        eng = pkg.Engine(1, n=n)
+        eng.set_weights(formulas.weights(n, scale=float(g[f'scale_n{n}'])).astype(np.float32))
+        for si, salt in enumerate(salts):
+            for ci, (depth, width, since_empty) in enumerate(configs):
+                want = g[f'values_n{n}'][si, ci]
+                if not want.any() and n == 5:
+                    continue                                    # (the one configuration the generator skips for n = 5)
+                tile = np.tile(salt[None, :], (len(boards), 1))
+                got = eng.boards_look_forward(boards, depth, width, since_empty, tile)
+                assert np.allclose(got, want, rtol=2e-6, atol=1e-6), (n, si, ci, np.abs(got - want).max())
+                after, _, changed = eng.boards_move_all(boards)
+                bi, di = np.nonzero((changed[:, None] >> np.arange(4)[None, :]) & 1)
+                vals = eng.boards_look_forward(after[bi, di], depth, width, since_empty, np.tile(salt[None, :], (len(bi), 1)))
+                best = np.zeros(len(boards), np.int64)
+                for b in range(len(boards)):
+                    top = -np.inf
+                    for d, v in zip(di[bi == b], vals[bi == b]):
+                        if v > top:
+                            top, best[b] = v, d
+                assert np.array_equal(best, g[f'best_dir_n{n}'][si, ci]), (n, si, ci)
+        # no salt = zeros; a full board has no chance node to sample: NaN where the reference divides by zero
+        assert np.array_equal(eng.boards_look_forward(boards, 2, 3, 6), eng.boards_look_forward(boards, 2, 3, 6, np.zeros((len(boards), 2), np.uint64)))
+        full = np.arange(1, 17, dtype=np.uint8).reshape(1, 4, 4) % 11 + 1
+        assert np.isnan(eng.boards_look_forward(full, 1, 2, 16)[0]) and np.isfinite(eng.boards_look_forward(full, 0, 2, 16)[0])
+        eng.close()
+
+
+def test_trial_with_lookahead_reproduces_the_reference_trial(api, golden):
+    """QAgent.trial(depth=2, width=3, since_empty=9) — Game.trial_run with look-ahead for all games in lock step on the device
+    (g2048_lookahead_steps) — against the REFERENCE's own trial of 4 games (tests/golden/make_golden4.py: game g draws its tiles
+    from lane lane0 + g of the RNG spec, its chance nodes keyed by that lane's RNG state at the move): same Games in the same
+    order, move for move, tile for tile."""
+    g = golden('trial_lookahead.npz')
+    n = int(g['n'])
+    agent = api.QAgent(name='t', storage='local', console='local', n=n, with_weights=False)
+    sizes = formulas.feature_sizes(n)
+    flat = formulas.weights(n, scale=float(g['scale'])).astype(np.float32)
+    offs = np.concatenate([[0], np.cumsum(sizes)[:-1]])
+    agent.weights = [flat[o:o + s] for o, s in zip(offs, sizes)]
+    agent.trial_seed = (int(g['seed']), int(g['lane0']))
+    import builtins
+    real_print = builtins.print
+    builtins.print = lambda *a, **k: None
+    try:
+        results = api.QAgent.trial(estimator=agent.evaluate, num=len(g['scores']), depth=int(g['depth']), width=int(g['width']),
+                                   since_empty=int(g['since_empty']), storage='local', console='local')
+    finally:
+        builtins.print = real_print
+    assert [r.score for r in results] == g['scores'].tolist() and [r.odometer for r in results] == g['odometers'].tolist()
+    for i, r in enumerate(results):
+        k = int(g['odometers'][i])
+        assert np.array_equal(r.row, g['rows'][i]) and np.array_equal(r.starting_position, g['starts'][i])
+        assert r.moves == g['moves'][i, :k].tolist()
+        assert [(t, p[0] * 4 + p[1]) for t, p in r.tiles] == [tuple(x) for x in g['tiles'][i, :k].tolist()]
+
+
 def test_trial_with_lookahead_plays_all_games_in_one_batch(api):
     """depth > 0 (game_logic.py:214-243 under trial_run): all games' trees go through lookahead.expectimax_values together.
     Every returned Game is a full record that replays to its final position; looking ahead does not play worse than greedy
@@ -381,20 +447,22 @@ def test_look_forward_matches_reference_fixture(api, golden):
             cells[i, :kk], tiles[i, :kk] = formulas.lookahead_draws(row, int(kk))
         return cells, tiles
 
-    import game2048.game_logic as gl
-    saved = list(gl._SAMPLER) if hasattr(gl, '_SAMPLER') else None
-    game_mod = importlib.import_module('2048_amd.game')
-    game_mod._SAMPLER[:] = [sampler]
-    try:
-        for ci, (depth, width, since_empty) in enumerate(g['configs']):
-            got = lookahead.expectimax_values(agent.engine, g['boards'], int(depth), int(width), int(since_empty), sampler)
-            assert np.allclose(got, g['values'][ci], rtol=1e-6, atol=1e-6), (depth, width, since_empty)
-            for bi in range(0, len(g['boards']), 3):
-                game = api.Game(row=g['boards'][bi].astype(np.int32))
-                assert game._find_best_move(agent.evaluate, int(depth), int(width), int(since_empty))[0] == g['best_dir'][ci, bi]
-    finally:
-        game_mod._SAMPLER[:] = []
-    del saved
+    # (lookahead.expectimax_values is the form for a CALLER-SUPPLIED sampler — here the NumPy-keyed draws of the round-2 fixture,
+    # which no device stream can reproduce; Game._find_best_move and QAgent.trial draw from the device's own spec and are pinned
+    # by test_device_look_forward_matches_the_reference / test_trial_with_lookahead_reproduces_the_reference_trial)
+    eng = agent.engine
+    for ci, (depth, width, since_empty) in enumerate(g['configs']):
+        got = lookahead.expectimax_values(eng, g['boards'], int(depth), int(width), int(since_empty), sampler)
+        assert np.allclose(got, g['values'][ci], rtol=1e-6, atol=1e-6), (depth, width, since_empty)
+        after, _, changed = eng.boards_move_all(g['boards'])
+        for bi in range(0, len(g['boards']), 3):
+            dirs = [d for d in range(4) if (changed[bi] >> d) & 1]
+            vals = lookahead.expectimax_values(eng, after[bi, dirs], int(depth), int(width), int(since_empty), sampler)
+            best, top = 0, -np.inf
+            for d, v in zip(dirs, vals):                       # first maximum, strict '>' (game_logic.py:150-161)
+                if v > top:
+                    best, top = d, v
+            assert best == g['best_dir'][ci, bi]
 
 
 def test_reference_written_pickles_load(api, golden, tmp_path, monkeypatch):
