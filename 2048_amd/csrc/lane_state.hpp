@@ -22,11 +22,7 @@ __device__ __forceinline__ Board ld_board(const uint4* p, size_t i) {
     b.r[0] = v.x; b.r[1] = v.y; b.r[2] = v.z; b.r[3] = v.w;
     return b;
 }
-#ifdef G2048_EXP_NT_STORES      // (experiment: the lane state streamed past the caches)
-#define G2048_ST(ptr, val) __builtin_nontemporal_store((val), (ptr))
-#else
 #define G2048_ST(ptr, val) (*(ptr) = (val))
-#endif
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void st_board(uint4* p, size_t i, const Board& b) {
@@ -161,21 +157,12 @@ __device__ __forceinline__ Moved pick(const Moves4& mv, uint32_t d) {
 // so that a pending gather holds one address register instead of a 64-bit pair — was measured: same register count after
 // allocation, k_td_play 0.200 -> 0.210 ms.  Plain indexing it is.)
 // (the slots handed to ld_w are memory slots: memory_slots<N>, features.hpp)
-#ifdef G2048_EXP_NOGATHER        // (experiment: what k_td_play costs without its table reads)
-__device__ __forceinline__ float ld_w(const float* __restrict__ w, uint32_t slot) { return __uint_as_float(0x30000000u | (slot & 0xFFFFu)); }
-#else
 __device__ __forceinline__ float ld_w(const float* __restrict__ w, uint32_t slot) { return w[slot]; }
-#endif
 
-// the gather of feature f: the f_6 features' 361 MB of tables (n = 6, f >= 21) have next to no reuse in a CU's 32 KB L1
-#ifndef G2048_HEX_LOAD          // 0: plain load; 1: nontemporal (L1 bypass)
-#define G2048_HEX_LOAD 0
-#endif
+// the gather of feature f (a non-temporal form for the f_6 tables, whose 361 MB have next to no reuse in a CU's 32 KB L1, was
+// measured: no difference — the L1 miss path carries the request either way)
 template <int N>
 __device__ __forceinline__ float ld_w_f(const float* __restrict__ w, uint32_t slot, int f) {
-#if G2048_HEX_LOAD == 1
-    if (N == 6 && f >= 21) return __builtin_nontemporal_load(w + slot);
-#endif
     return ld_w(w, slot);
 }
 

@@ -215,7 +215,7 @@ def test_eval_select_config3_full_size():
     eng.close()
 
 
-@pytest.mark.parametrize('n', [2, 4, 5, 6])
+@pytest.mark.parametrize('n', [2, 3, 4, 5, 6])
 def test_update_linearity_full_size(n):
     """Size-independent property at 2^20 records: every record adds dw to 8 * num_feat slots, so the table sum
     moves by 8 * F * sum(dw); and update(+dw) followed by update(-dw) restores the table."""
@@ -509,6 +509,56 @@ def test_td_config4_full_size_owner_path(n):
         got = (eng.get_weights().astype(np.float64) - w.astype(np.float64)).sum()
         assert abs(got - total) <= 1e-6 * mass + 1e-6, (got, total)
     assert not rb.game_over(eng.get_boards()[(eng.get_carry()[2] & 2) == 0]).any()    # no dead board stays live
+    # ---- bursts with NO accessor in between (round 4): an accessor restores the lane order and drops a pending re-order, so the
+    # step-by-step part above never runs the kernels the bench times between its barriers — k_td_play_hot<5, 512, PERM = true>,
+    # steps on re-ordered lanes, a replan mid-burst.  17 steps = one sort period (8) + its lag (2) + seven steps on permuted lanes.
+    K = 17
+    w = formulas.weights(n, scale=2.0 ** -6)
+    eng.set_weights(w)
+    boards0, scores0, rng0 = eng.get_boards(), eng.get_scores(), eng.get_rng()
+    prev0, label0, flags0 = eng.get_carry()
+    # (a) alpha = 0: no record changes the table, so the float64 oracle can replay the slice through all K steps
+    lanes = rb.Lanes(boards0[lo:hi], scores0[lo:hi])
+    lanes.prev, lanes.label = prev0[lo:hi].copy(), label0[lo:hi].astype(np.float64)
+    lanes.has_prev, lanes.done = (flags0[lo:hi] & 1).astype(bool), (flags0[lo:hi] & 2).astype(bool)
+    draws = helpers.SpecDraws(rng0[lo:hi].copy())
+    w64 = w.astype(np.float64)
+    for _ in range(K):
+        rb.td_step(n, w64, lanes, 0.0, draws)
+    moves0 = eng.stats()['moves']
+    eng.td_steps(0.0, K)
+    boards1, scores1 = eng.get_boards(), eng.get_scores()
+    prev1, label1, flags1 = eng.get_carry()
+    assert np.array_equal(boards1[lo:hi], lanes.boards) and np.array_equal(scores1[lo:hi], lanes.scores)
+    assert np.array_equal(eng.get_rng()[lo:hi], draws.state)
+    alive = ~lanes.done
+    assert np.array_equal(prev1[lo:hi][alive], lanes.prev[alive]) and np.array_equal(label1[lo:hi].astype(np.float64), lanes.label)
+    assert np.array_equal((flags1[lo:hi] & 2).astype(bool), lanes.done)
+    assert np.array_equal(eng.get_weights(), w)                               # alpha = 0: the table did not move
+    assert 0 < eng.stats()['moves'] - moves0 <= K * int(((flags0 & 2) == 0).sum())
+    # (b) a small alpha: the records of a lane telescope — sum_t dw1_t = (score_K - score_0 + label_K - label_0) alpha / F for a
+    # lane that carried a state into the burst, and a game that ends inside it closes with -label_K alpha / F (r_learning.py:240,248)
+    # — so the table's total change over the burst is known from the lane state before and after, whatever order the lanes were in
+    small = alpha * 2.0 ** -12
+    boards0, scores0 = boards1, scores1
+    label0, flags0 = label1, flags1
+    eng.td_steps(small, K)
+    scores1 = eng.get_scores()
+    _, label1, flags1 = eng.get_carry()
+    live0 = (flags0 & 2) == 0
+    had = live0 & ((flags0 & 1) != 0)
+    ended = live0 & ((flags1 & 2) != 0)
+    gain = (scores1.astype(np.float64) - scores0) + label1.astype(np.float64)
+    per_lane = np.where(had, gain - label0.astype(np.float64), 0.0)
+    # (a lane without a carried state makes no record on its first move; its later records telescope from that move's value,
+    # which the lane state does not show: at this point of the test every live lane has a state)
+    assert not (live0 & ~had).any()
+    per_lane = per_lane - np.where(ended, label1.astype(np.float64), 0.0)
+    total = 8.0 * F * per_lane[live0].sum() * small / F
+    mass = 8.0 * small * (np.abs(scores1.astype(np.float64) - scores0) + np.abs(label1) + np.abs(label0))[live0].sum()
+    got = (eng.get_weights().astype(np.float64) - w64).sum()
+    assert abs(got - total) <= 2e-5 * mass + 1e-6, (got, total, mass)
+    assert not rb.game_over(eng.get_boards()[(eng.get_carry()[2] & 2) == 0]).any()
     eng.close()
 
 

@@ -29,11 +29,30 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TARGET = 'hipv4-amdgcn-amd-amdhsa--gfx950'
 
 
-def extract_code_object(so, workdir):
-    fat, co = os.path.join(workdir, 'fatbin'), os.path.join(workdir, 'code.co')
+def extract_code_objects(so, workdir):
+    """Every gfx950 code object of the library: one per translation unit (the .hip_fatbin section holds their offload bundles
+    back to back)."""
+    fat = os.path.join(workdir, 'fatbin')
     subprocess.check_call([f'{LLVM}/llvm-objcopy', '--dump-section', f'.hip_fatbin={fat}', so, os.path.join(workdir, 'copy.so')])
-    subprocess.check_call([f'{LLVM}/clang-offload-bundler', '--unbundle', '--type=o', f'--input={fat}', f'--targets={TARGET}', f'--output={co}'])
-    return co
+    data = open(fat, 'rb').read()
+    magic = b'__CLANG_OFFLOAD_BUNDLE__'
+    starts = [i for i in range(len(data)) if data.startswith(magic, i)]
+    out = []
+    for k, a in enumerate(starts):
+        part, co = os.path.join(workdir, f'bundle{k}'), os.path.join(workdir, f'code{k}.co')
+        with open(part, 'wb') as f:
+            f.write(data[a:starts[k + 1] if k + 1 < len(starts) else len(data)])
+        subprocess.check_call([f'{LLVM}/clang-offload-bundler', '--unbundle', '--type=o', f'--input={part}', f'--targets={TARGET}', f'--output={co}'])
+        out.append(co)
+    return out
+
+
+def extract_code_object(so, workdir, containing='k_td_play'):
+    """The code object that holds the kernels named `containing` (tools/isa_mix.py and friends look at one kernel family)."""
+    for co in extract_code_objects(so, workdir):
+        if any(containing in k for k in kernel_notes(co)):
+            return co
+    raise SystemExit(f'no code object with {containing} kernels in {so}')
 
 
 def kernel_notes(co):
@@ -213,8 +232,12 @@ def main():
     so = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, '2048_amd', 'lib2048_hip.so')
     failures = []
     with tempfile.TemporaryDirectory() as tmp:
-        co = extract_code_object(so, tmp)
-        notes = kernel_notes(co)
+        cos = extract_code_objects(so, tmp)
+        notes, where = {}, {}
+        for co_ in cos:
+            for k_, v_ in kernel_notes(co_).items():
+                notes[k_], where[k_] = v_, co_
+        print(f'[codeobj] {len(cos)} code objects (translation units), {len(notes)} kernels')
         # the kernels whose gathers land in registers outside the allocator's range (choose_hot, choose_small<3>)
         guarded = {'k_td_play_hot': 4 * 17, 'k_td_play_lds3': 2 * 52, 'k_eval_select_lds3': 2 * 52}
         cap = {'k_td_play_hot': 168, 'k_td_play_lds3': 168, 'k_eval_select_lds3': 128}      # first VGPR outside the allocator's range (amdgpu_waves_per_eu)
@@ -236,7 +259,7 @@ def main():
             if d['private_segment_fixed_size'] != 0 or d['vgpr_spill_count'] != 0:
                 failures.append(f'{name}: scratch {d["private_segment_fixed_size"]} B, {d["vgpr_spill_count"]} spilled VGPRs — the register '
                                 f'allocator ran out below the cap, and a spilled value is how an in-flight register gets saved')
-            ins = disassemble(co, k)
+            ins = disassemble(where[k], k)
             loads = sum(1 for _, x, _ in ins if x.startswith('global_load_dword '))
             fences = sum(1 for _, x, _ in ins if x.startswith('s_waitcnt vmcnt(0)'))
             bad = check_inflight(ins)
@@ -270,7 +293,7 @@ def main():
         for k in sorted(notes):
             if 'k_apply_orbits' not in k:
                 continue
-            ins = disassemble(co, k)
+            ins = disassemble(where[k], k)
             unguarded = check_store_release(ins)
             short = 'k_apply_orbits_mean' if 'k_apply_orbits_mean' in k else 'k_apply_orbits'
             print(f'[codeobj] {short}: {sum(1 for _, x, _ in ins if x.startswith("s_barrier"))} s_barrier, {unguarded} with a store in front and no vmcnt(0) wait')
