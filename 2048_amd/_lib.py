@@ -128,11 +128,14 @@ def load(backend=None):
             raise G2048Error(ERR_NODEV, f'{path} is not built; run __graft_entry__.build() '
                                         + ('(hipcc --offload-arch=gfx950).  There is no CPU fallback.' if backend == 'hip' else '(g++ -fopenmp csrc/cpu_ref.cpp).'))
         lib = ctypes.CDLL(path)
+        experiment = backend == 'hip' and bool(os.environ.get('G2048_LIB'))      # (a timing build of tools/exp, possibly of an older ABI)
         for name, (res, args) in SIGNATURES.items():
+            if experiment and not hasattr(lib, name):
+                continue
             fn = getattr(lib, name)          # AttributeError here = header and library disagree
             fn.restype = res
             fn.argtypes = args
-        if lib.g2048_abi_version() != 3:
+        if lib.g2048_abi_version() != 3 and not experiment:
             raise G2048Error(ERR_STATE, 'ABI version mismatch')
         _libs[backend] = lib
     return _libs[backend]

@@ -159,6 +159,30 @@ def side_workload(pkg, args):
         out = dict(workload='BASELINE config 2: env step only, random valid direction', batch=B, steps=args.steps,
                    value=B * args.steps / (ms * 1e-3), unit='board-steps/s', ms_per_step=ms / args.steps,
                    algorithmic_GBps=72 * B * args.steps / (ms * 1e-3) / 1e9)
+    elif args.workload == 'lookahead':
+        # Game.look_forward (game_logic.py:214-243) for many positions at once: every tree expanded, evaluated and reduced on the
+        # device (csrc/lookahead.hip).  since_empty = 17 makes every node an inner node (no early leaves), so a call is exactly
+        # roots x (4 width)^depth leaf slots; the boards travel over PCIe once per call (16 B per root against ~100 B x leaves).
+        B = 65536 if args.batch == 1 << 20 else args.batch
+        n, depth, width = args.n_tuple, 2, 4
+        eng = pkg.Engine(B, n=n, seed=2048)
+        eng.step_random(120)
+        eng.init_weights(seed=7, scale=0.01)
+        boards = eng.get_boards()
+        after, _, changed = eng.boards_move_all(boards)
+        roots = np.ascontiguousarray(after[np.arange(B), np.argmax((changed[:, None] >> np.arange(4)[None, :]) & 1, axis=1)])   # one afterstate per lane
+        for _ in range(max(1, args.warmup // 8)):
+            eng.boards_look_forward(roots, depth, width, 17)
+        t0 = time.perf_counter()
+        reps = max(1, args.steps // 8)
+        for _ in range(reps):
+            v = eng.boards_look_forward(roots, depth, width, 17)
+        dt = (time.perf_counter() - t0) / reps
+        leaves = B * (4 * width) ** depth
+        by = 16 + 4 * NUM_FEAT[n] + 4 + 2                   # a leaf slot: board + F gathers + value + valid / kind bytes
+        out = dict(workload=f'look-ahead: V_{depth}(board) of {B} positions, width {width}, every node expanded, {n}-tuple table (g2048_boards_look_forward)',
+                   batch=B, steps=reps, value=B / dt, unit='positions/s', leaf_slots_per_s=leaves / dt, ms_per_call=dt * 1e3,
+                   algorithmic_GBps=by * leaves / dt / 1e9, finite=bool(np.isfinite(v).all()))
     else:
         B = 262144 if args.batch == 1 << 20 else args.batch
         n = 3 if args.n_tuple == 5 else args.n_tuple
@@ -470,7 +494,7 @@ def main():
     ap.add_argument('--trained-steps', type=int, default=3000,
                     help='after the mean-rule leg: train this many more steps under the mean rule, then time K steps on the trained agent\'s boards (0: skip)')
     ap.add_argument('--no-mean-line', action='store_true', help='skip the secondary measurement of the per-slot mean rule')
-    ap.add_argument('--workload', default='td', choices=['td', 'env', 'eval'],
+    ap.add_argument('--workload', default='td', choices=['td', 'env', 'eval', 'lookahead'],
                     help='td = BASELINE config 4 (the metric); env = config 2 (65 536 lanes, env step only); eval = config 3 '
                          '(262 144 lanes, n=3 evaluate + greedy select); env/eval print a reduced JSON line')
     ap.add_argument('--rule', default='sum', choices=['sum', 'mean'],
