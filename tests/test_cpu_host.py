@@ -40,6 +40,36 @@ def test_library_exports_every_declared_symbol():
     assert lib.g2048_strerror(-5) == b'no usable GPU'
 
 
+def test_explicit_cpu_backend_does_not_need_the_hip_library(tmp_path):
+    """`Engine(backend='cpu')` is an explicit choice and must be honoured on a box that has no lib2048_hip.so at all (the advisor's
+    round-3 finding: the geometry helpers used to load the default backend): a fresh interpreter with G2048_BACKEND unset and the
+    HIP library's path pointing at a file that does not exist."""
+    import subprocess
+    import sys
+    code = f"""
+import importlib, os, sys
+sys.path.insert(0, {ROOT!r})
+os.environ.pop('G2048_BACKEND', None)
+os.environ['G2048_LIB'] = {str(tmp_path / 'no_such_lib2048_hip.so')!r}
+pkg = importlib.import_module('2048_amd')
+eng = pkg.Engine(8, n=4, backend='cpu')
+eng.init_weights(seed=1)
+eng.td_steps(0.01, 3)
+assert eng.stats()['moves'] == 24 and eng.slots == 17 * 65536
+offs, sizes = importlib.import_module('2048_amd.engine').feature_layout(4, 'cpu')
+assert len(offs) == 17
+try:
+    pkg.Engine(8, n=4)                       # the default backend is still the HIP library, and it is still not there
+except Exception as e:
+    assert 'not built' in str(e), e
+else:
+    raise SystemExit('the default backend must not fall back')
+print('ok')
+"""
+    res = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0 and res.stdout.strip().endswith('ok'), res.stderr[-1500:]
+
+
 def test_no_gpu_means_loud_failure_not_a_cpu_path():
     n = ctypes.c_int(-1)
     pkg.load_library().g2048_device_count(ctypes.byref(n))
