@@ -891,6 +891,12 @@ constexpr uint32_t HEX_SLOTS = 2u * HEX_SIZE;               // both orbit tables
 constexpr uint32_t HEX_CHUNK = 16384u;                      // slots per chunk: 128 KB of 64-bit LDS sums
 constexpr uint32_t HEX_BINS = (HEX_SLOTS + HEX_CHUNK - 1) / HEX_CHUNK;     // 920
 constexpr uint32_t HEX_PART_PAIRS = 1u << 16;               // an owner workgroup takes at most this many pairs
+// Round 4: a chunk's run is filled through EIGHT cursors, one per group of record tiles (tile % 8).  A fresh agent's pairs sit in
+// a handful of chunks, and every tile of 1 024 records reserved its share of such a chunk with a returning atomic on ONE
+// cursor: 1 024 same-address returning atomics complete one after the other (~50 ns each, see k_td_play's block counters) —
+// the 64 us of k_hex_scatter.  k_hex_count counts per (chunk, group) — a workgroup's tiles all belong to one group — so the
+// eight sub-runs are exact and lie back to back: the owners still see one contiguous run per chunk.
+constexpr uint32_t HEX_GROUPS = 8;
 constexpr uint32_t HEX_MAX_WORK = 4096;
 
 struct HexWork {        // one owner workgroup
@@ -898,9 +904,9 @@ struct HexWork {        // one owner workgroup
 };
 
 struct HexBufs {
-    uint32_t* count;        // [HEX_BINS] pairs per chunk (this step)
+    uint32_t* count;        // [HEX_BINS][HEX_GROUPS] pairs per chunk and tile group (this step)
     uint32_t* base;         // [HEX_BINS + 1] first pair of each chunk
-    uint32_t* cursor;       // [HEX_BINS] next free pair of each chunk during the scatter
+    uint32_t* cursor;       // [HEX_BINS][HEX_GROUPS] next free pair of each (chunk, group) sub-run during the scatter
     uint2* pairs;           // (slot in the two tables, dw bits)
     HexWork* work;          // [HEX_MAX_WORK]
     uint32_t* nwork;
@@ -954,73 +960,131 @@ __global__ __launch_bounds__(OWN_WG) void k_hex_count(TdRecs recs, uint32_t B, H
         for (int j = 0; j < HEX_PAIRS; ++j) atomicAdd(&hist[s[j] / HEX_CHUNK], 1u);
     }
     __syncthreads();
+    // (the grid is a multiple of HEX_GROUPS: every tile of 1 024 records this workgroup saw has tile % 8 == blockIdx.x % 8)
     for (uint32_t j = threadIdx.x; j < HEX_BINS; j += OWN_WG)
-        if (hist[j]) atomicAdd(&hb.count[j], hist[j]);
+        if (hist[j]) atomicAdd(&hb.count[j * HEX_GROUPS + (blockIdx.x % HEX_GROUPS)], hist[j]);
 }
 
-// one workgroup: scan the histogram, cut busy chunks into parts, clear the counters for the next step
+// one workgroup: scan the histogram, cut busy chunks into parts, clear the counters for the next step.  (Round 4: the work list
+// is written by all threads — a fresh agent's pairs sit in a handful of chunks of a hundred parts each, which one thread per
+// chunk used to write one after the other.)
 __global__ __launch_bounds__(OWN_WG) void k_hex_plan(HexBufs hb) {
-    __shared__ uint32_t pre[OWN_WG], wpre[OWN_WG];
-    const uint32_t j = threadIdx.x;
-    const uint32_t c = j < HEX_BINS ? hb.count[j] : 0u;
-    const uint32_t parts = (c + HEX_PART_PAIRS - 1) / HEX_PART_PAIRS;
-    pre[j] = c;
-    wpre[j] = parts;
-    __syncthreads();
-    for (uint32_t off = 1; off < OWN_WG; off <<= 1) {       // inclusive scans of the pair counts and of the part counts
-        const uint32_t a = j >= off ? pre[j - off] : 0u, b = j >= off ? wpre[j - off] : 0u;
-        __syncthreads();
-        pre[j] += a;
-        wpre[j] += b;
-        __syncthreads();
+    __shared__ uint32_t pre[OWN_WG], wpre[OWN_WG], cnt[OWN_WG], wtot[2][OWN_WG / 64];
+    const uint32_t j = threadIdx.x, lane = j & 63u, wave = j >> 6;
+    uint32_t cg[HEX_GROUPS], c = 0;
+#pragma unroll
+    for (uint32_t g = 0; g < HEX_GROUPS; ++g) {
+        cg[g] = j < HEX_BINS ? hb.count[j * HEX_GROUPS + g] : 0u;
+        c += cg[g];
     }
-    const uint32_t first = pre[j] - c, wfirst = wpre[j] - parts;
-    if (j < HEX_BINS) {
-        hb.base[j] = first;
-        hb.cursor[j] = first;
-        hb.count[j] = 0;
-        for (uint32_t k = 0; k < parts && wfirst + k < HEX_MAX_WORK; ++k) {
-            const uint32_t lo = (uint32_t)((uint64_t)c * k / parts), hi = (uint32_t)((uint64_t)c * (k + 1) / parts);
-            hb.work[wfirst + k] = HexWork{j, first + lo, hi - lo, parts > 1 ? 1u : 0u};
+    const uint32_t parts = (c + HEX_PART_PAIRS - 1) / HEX_PART_PAIRS;
+    // inclusive scans of the pair counts and of the part counts: inside the waves with shuffles, across them through 16 totals
+    uint32_t ic = c, ip = parts;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t uc = (uint32_t)__shfl_up((int)ic, off), up = (uint32_t)__shfl_up((int)ip, off);
+        if (lane >= (uint32_t)off) {
+            ic += uc;
+            ip += up;
         }
     }
+    if (lane == 63u) {
+        wtot[0][wave] = ic;
+        wtot[1][wave] = ip;
+    }
+    __syncthreads();
+    for (uint32_t k = 0; k < wave; ++k) {
+        ic += wtot[0][k];
+        ip += wtot[1][k];
+    }
+    pre[j] = ic;
+    wpre[j] = ip;
+    cnt[j] = c;
+    __syncthreads();
+    const uint32_t first = pre[j] - c;
+    if (j < HEX_BINS) {
+        hb.base[j] = first;
+        uint32_t at = first;
+#pragma unroll
+        for (uint32_t g = 0; g < HEX_GROUPS; ++g) {         // the chunk's eight sub-runs, back to back
+            hb.cursor[j * HEX_GROUPS + g] = at;
+            hb.count[j * HEX_GROUPS + g] = 0;
+            at += cg[g];
+        }
+    }
+    const uint32_t nwork = wpre[OWN_WG - 1] < HEX_MAX_WORK ? wpre[OWN_WG - 1] : HEX_MAX_WORK;
     if (j == OWN_WG - 1) {
         hb.base[HEX_BINS] = pre[j];
-        *hb.nwork = wpre[j] < HEX_MAX_WORK ? wpre[j] : HEX_MAX_WORK;
+        *hb.nwork = nwork;
+    }
+    // work item w belongs to the chunk whose inclusive part count first exceeds w
+    for (uint32_t w = j; w < nwork; w += OWN_WG) {
+        uint32_t lo = 0, hi = OWN_WG - 1;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (wpre[mid] > w)
+                hi = mid;
+            else
+                lo = mid + 1;
+        }
+        const uint32_t bin = lo, cb = cnt[bin], pb = (cb + HEX_PART_PAIRS - 1) / HEX_PART_PAIRS, k = w - (wpre[bin] - pb), fb = pre[bin] - cb;
+        const uint32_t plo = (uint32_t)((uint64_t)cb * k / pb), phi = (uint32_t)((uint64_t)cb * (k + 1) / pb);
+        hb.work[w] = HexWork{bin, fb + plo, phi - plo, pb > 1 ? 1u : 0u};
     }
 }
 
+// Round 4: the tile's pairs are first put in chunk order in LDS (128 KB: 1 024 records x 16 pairs) and then copied out, so that
+// consecutive lanes write consecutive pairs of a chunk's run.  The round-3 form stored every pair straight from the lane that made
+// it — sixteen 8-byte stores per lane into sixteen different runs, 15.3 M separate L1 accesses per launch with the L1 busy 90 % of
+// the kernel's 64 us (TCP_TOTAL_CACHE_ACCESSES / TCP_GATE_EN1, profiles/r04_pmc_summary.json): a request-rate bound like k_td_play's.
 template <int N>
 __global__ __launch_bounds__(OWN_WG) void k_hex_scatter(TdRecs recs, uint32_t B, HexBufs hb) {
-    __shared__ uint32_t hist[HEX_BINS], lbase[HEX_BINS];
+    __shared__ uint2 stage[OWN_WG * HEX_PAIRS];
+    __shared__ uint32_t hist[HEX_BINS], lofs[HEX_BINS], lbase[HEX_BINS], wtot[OWN_WG / 64];
     const uint32_t total = B + *recs.qcount;
     const uint32_t ntiles = (total + OWN_WG - 1) / OWN_WG;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {        // (uniform trip count: barriers inside)
         for (uint32_t j = threadIdx.x; j < HEX_BINS; j += OWN_WG) hist[j] = 0;
         __syncthreads();
         Packed p;
         float dw = 0.0f;
-        uint32_t s[HEX_PAIRS];
+        uint32_t s[HEX_PAIRS], rank[HEX_PAIRS];
         const bool ok = hex_load_record(recs, B, tile * OWN_WG + threadIdx.x, total, p, dw);
         if (ok) {
             hex_record_slots<N>(p, s);
 #pragma unroll
-            for (int j = 0; j < HEX_PAIRS; ++j) atomicAdd(&hist[s[j] / HEX_CHUNK], 1u);
+            for (int j = 0; j < HEX_PAIRS; ++j) rank[j] = atomicAdd(&hist[s[j] / HEX_CHUNK], 1u);      // place inside the tile's share of the chunk
         }
         __syncthreads();
-        for (uint32_t j = threadIdx.x; j < HEX_BINS; j += OWN_WG) {
-            const uint32_t h = hist[j];
-            lbase[j] = h ? atomicAdd(&hb.cursor[j], h) : 0u;       // room for this tile's pairs in chunk j
-            hist[j] = 0;                                            // becomes the tile's running count
+        // one thread per chunk: room in the chunk's run (its group's cursor), and the chunk's offset in the staging area (an
+        // exclusive scan of the histogram: wave scans + the 16 wave totals)
+        const uint32_t h = threadIdx.x < HEX_BINS ? hist[threadIdx.x] : 0u;
+        uint32_t inc = h;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)inc, off);
+            if (lane >= (uint32_t)off) inc += up;
         }
+        if (lane == 63u) wtot[wave] = inc;
+        if (threadIdx.x < HEX_BINS) lbase[threadIdx.x] = h ? atomicAdd(&hb.cursor[threadIdx.x * HEX_GROUPS + (tile % HEX_GROUPS)], h) : 0u;
+        __syncthreads();
+        uint32_t before = 0;
+        for (uint32_t k = 0; k < wave; ++k) before += wtot[k];
+        if (threadIdx.x < HEX_BINS) lofs[threadIdx.x] = before + inc - h;
+        uint32_t npairs = 0;
+        for (uint32_t k = 0; k < OWN_WG / 64; ++k) npairs += wtot[k];
         __syncthreads();
         if (ok) {
             const uint32_t bits = recs.unit ? __float_as_uint(1.0f) : __float_as_uint(dw);
 #pragma unroll
-            for (int j = 0; j < HEX_PAIRS; ++j) {
-                const uint32_t bin = s[j] / HEX_CHUNK;
-                hb.pairs[lbase[bin] + atomicAdd(&hist[bin], 1u)] = make_uint2(s[j], bits);
-            }
+            for (int j = 0; j < HEX_PAIRS; ++j) stage[lofs[s[j] / HEX_CHUNK] + rank[j]] = make_uint2(s[j], bits);
+        }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < npairs; i += OWN_WG) {
+            const uint2 pr = stage[i];
+            const uint32_t bin = pr.x / HEX_CHUNK;
+            hb.pairs[lbase[bin] + (i - lofs[bin])] = pr;
         }
         __syncthreads();
     }
@@ -1043,9 +1107,19 @@ __global__ __launch_bounds__(OWN_WG) void k_hex_owner(float* D, float* Dc, const
     for (uint32_t j = threadIdx.x; j < HEX_CHUNK; j += OWN_WG) acc[j] = 0ull;
     __syncthreads();
     const uint32_t lo = wk.bin * HEX_CHUNK;
-    for (uint32_t k = threadIdx.x; k < wk.count; k += OWN_WG) {
-        const uint2 pr = hb.pairs[wk.first + k];
-        atomicAdd(&acc[pr.x - lo], packed_add(__uint_as_float(pr.y), scale, cbits));
+    // eight pairs per thread in flight: one load per turn left the 64 turns of a 65 536-pair part waiting for memory one after
+    // the other (52 us for 16.8 M adds the LDS could take in 7)
+    constexpr uint32_t HU = 8;
+    for (uint32_t k0 = 0; k0 < wk.count; k0 += HU * OWN_WG) {
+        uint2 pr[HU];
+#pragma unroll
+        for (uint32_t u = 0; u < HU; ++u) {
+            const uint32_t k = k0 + u * OWN_WG + threadIdx.x;
+            pr[u] = hb.pairs[wk.first + (k < wk.count ? k : wk.count - 1u)];
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < HU; ++u)
+            if (k0 + u * OWN_WG + threadIdx.x < wk.count) atomicAdd(&acc[pr[u].x - lo], packed_add(__uint_as_float(pr[u].y), scale, cbits));
     }
     __syncthreads();
     const unsigned long long cmask = (1ull << cbits) - 1ull;
@@ -1855,11 +1929,11 @@ int build_slices(g2048_ctx* c) {
             if ((rc = dalloc(c, &c->D2, c->owned_total))) return rc;
             HIP_TRY(c, hipMemset(c->D2, 0, (size_t)c->owned_total * 4));
             if (c->n == 6 && c->B <= (1u << 23)) {       // binned update of the f_6 orbits: 16 pairs per record, main + terminal
-                if ((rc = dalloc(c, &c->hex.count, HEX_BINS)) || (rc = dalloc(c, &c->hex.base, HEX_BINS + 1)) ||
-                    (rc = dalloc(c, &c->hex.cursor, HEX_BINS)) || (rc = dalloc(c, &c->hex.pairs, (size_t)2 * HEX_PAIRS * c->B)) ||
+                if ((rc = dalloc(c, &c->hex.count, HEX_BINS * HEX_GROUPS)) || (rc = dalloc(c, &c->hex.base, HEX_BINS + 1)) ||
+                    (rc = dalloc(c, &c->hex.cursor, HEX_BINS * HEX_GROUPS)) || (rc = dalloc(c, &c->hex.pairs, (size_t)2 * HEX_PAIRS * c->B)) ||
                     (rc = dalloc(c, &c->hex.work, HEX_MAX_WORK)) || (rc = dalloc(c, &c->hex.nwork, 1)))
                     return rc;
-                HIP_TRY(c, hipMemset(c->hex.count, 0, HEX_BINS * 4));
+                HIP_TRY(c, hipMemset(c->hex.count, 0, HEX_BINS * HEX_GROUPS * 4));
             }
         }
         if (int rc = dalloc(c, &c->slices, MAX_SLICES)) return rc;
