@@ -1494,6 +1494,7 @@ struct g2048_ctx {
         uint32_t sort_values = 1;       // the key also tells the big tiles' values apart (hashed; G2048_SORT_VALUES=0: positions only, round 2's key)
         uint32_t sort_lag = 2;          // steps between the boards a sort looks at and the step that applies it (G2048_SORT_LAG; 0 = sort in line)
         int hex_bins = 1;               // n = 6: f_6 orbits through k_hex_* (0: k_td_update_tail's scattered atomics)
+        int comm_rsag = 0;              // g2048_allreduce_deltas as ncclReduceScatter + ncclAllGather (G2048_COMM_ALGO=rsag)
         int delta_accum = 0;            // multi-GPU epoch delta: 0 = W - W0 when it is asked for, 1 = every add of a step mirrored in an accumulator
         int mean_one_pass = 1;          // per-slot mean rule: counts packed beside the sums (0: always two accumulation passes)
         int play_hot = 1;               // k_td_play reads the first entries of every four-cell table (memory order) from an LDS copy (n >= 4, big batches): -8 % per step
@@ -1591,6 +1592,7 @@ void read_knobs(g2048_ctx* c) {
     if (const char* e = getenv("G2048_PLAY_HOT")) k.play_hot = atoi(e);
     if (const char* e = getenv("G2048_MEAN_ONE_PASS")) k.mean_one_pass = atoi(e);
     if (const char* e = getenv("G2048_HEX_BINS")) k.hex_bins = atoi(e);
+    if (const char* e = getenv("G2048_COMM_ALGO")) k.comm_rsag = strcmp(e, "rsag") == 0;
     if (const char* e = getenv("G2048_SORT_EVERY")) k.sort_every = (uint32_t)atoi(e);
     if (const char* e = getenv("G2048_SORT_MIN")) k.sort_min_batch = (uint32_t)atoi(e);
     if (const char* e = getenv("G2048_SORT_LAG")) k.sort_lag = (uint32_t)atoi(e);
@@ -3193,12 +3195,14 @@ int g2048_weights_device_ptr(g2048_ctx* c, void** ptr, int64_t* count) {
     return G2048_OK;
 }
 
+constexpr size_t DELTA_SLACK = 256 * 64;       // floats: padding of the payload to nranks chunks of a multiple of 256 (up to 64 ranks)
 static int ensure_delta(g2048_ctx* c) {
     int rc;
     if (!c->w0 && (rc = dalloc(c, &c->w0, c->slots))) return rc;
     if (!c->delta) {
-        if ((rc = dalloc(c, &c->delta, c->slots))) return rc;
-        HIP_TRY(c, hipMemsetAsync(c->delta, 0, c->slots * 4, c->stream));
+        // (a zero tail behind the table's slots: the reduce-scatter form of the exchange reads whole, padded chunks — DELTA_SLACK)
+        if ((rc = dalloc(c, &c->delta, c->slots + DELTA_SLACK))) return rc;
+        HIP_TRY(c, hipMemsetAsync(c->delta, 0, (c->slots + DELTA_SLACK) * 4, c->stream));
     }
     return G2048_OK;
 }
@@ -3308,6 +3312,8 @@ struct Rccl {
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*ReduceScatter)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;      // optional
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;                        // optional
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;          // optional: what the communicator itself reports
     ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
@@ -3327,6 +3333,8 @@ Rccl* rccl() {
     r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.lib, "ncclCommInitRank"));
     r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.lib, "ncclCommDestroy"));
     r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(dlsym(r.lib, "ncclAllReduce"));
+    r.ReduceScatter = reinterpret_cast<decltype(r.ReduceScatter)>(dlsym(r.lib, "ncclReduceScatter"));
+    r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(r.lib, "ncclAllGather"));
     r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.lib, "ncclGetErrorString"));
     r.CommCount = reinterpret_cast<decltype(r.CommCount)>(dlsym(r.lib, "ncclCommCount"));
     r.CommUserRank = reinterpret_cast<decltype(r.CommUserRank)>(dlsym(r.lib, "ncclCommUserRank"));
@@ -3416,16 +3424,34 @@ int g2048_allreduce_deltas(g2048_ctx* c) {
     Rccl* r = rccl();
     const size_t n = c->slots;
     if (int rc = refresh_delta(c)) return rc;
+    // The sum over the ranks of `count` floats of `src`, into `dst`.  Default: one ncclAllReduce.  G2048_COMM_ALGO=rsag: the same sum
+    // as ncclReduceScatter + ncclAllGather (every rank reduces 1 / nranks of the payload and hands it round): on MI355X's
+    // point-to-point xGMI (7 links per GPU) a ring all-reduce is bound by ONE link (2 (N-1)/N S / 153 GB/s: 4.4 ms for the n = 6
+    // table at N = 8) where the direct pair keeps all seven busy (2 S / N per link: 0.63 ms) — which of the two RCCL's own
+    // ncclAllReduce picks on a given box is for the 8-GPU run to show (the line's `comm` block times the exchange); both forms
+    // give the same sums up to fp32 reduction order.
+    auto exchange = [&](const float* src, float* dst, size_t count) -> int {      // (src may be dst; both have DELTA_SLACK floats of room, src's tail is zero)
+        if (c->knob.comm_rsag && r->ReduceScatter && r->AllGather && c->comm_ranks <= 64) {
+            const size_t ranks = (size_t)c->comm_ranks, chunk = ((count + ranks - 1) / ranks + 255) / 256 * 256;
+            float* mine = dst + (size_t)c->comm_rank * chunk;
+            ncclResult_t e = r->ReduceScatter(src, mine, chunk, ncclFloat32, ncclSum, (ncclComm_t)c->comm, c->stream);
+            if (e != ncclSuccess) return rccl_fail(c, "ncclReduceScatter", e);
+            e = r->AllGather(mine, dst, chunk, ncclFloat32, (ncclComm_t)c->comm, c->stream);
+            if (e != ncclSuccess) return rccl_fail(c, "ncclAllGather", e);
+            return G2048_OK;
+        }
+        const ncclResult_t e = r->AllReduce(src, dst, count, ncclFloat32, ncclSum, (ncclComm_t)c->comm, c->stream);
+        return e == ncclSuccess ? G2048_OK : rccl_fail(c, "ncclAllReduce", e);
+    };
     if (c->update_rule == 1) {
-        if (int rc = ensure_pack(c, 2 * n)) return rc;
+        if (int rc = ensure_pack(c, 2 * n + DELTA_SLACK)) return rc;
         k_delta_pack_touched<<<2048, WG, 0, c->stream>>>(c->delta, c->pack, n, 0);
-        ncclResult_t e = r->AllReduce(c->pack, c->pack, 2 * n, ncclFloat32, ncclSum, (ncclComm_t)c->comm, c->stream);
-        if (e != ncclSuccess) return rccl_fail(c, "ncclAllReduce", e);
+        if (c->knob.comm_rsag) HIP_TRY(c, hipMemsetAsync(c->pack + 2 * n, 0, DELTA_SLACK * sizeof(float), c->stream));
+        if (int rc = exchange(c->pack, c->pack, 2 * n)) return rc;
         k_delta_add_mean<<<2048, WG, 0, c->stream>>>(c->w, c->w0, c->pack, c->knob.delta_accum ? c->delta : nullptr, n, 0);
     } else {
-        if (int rc = ensure_pack(c, n)) return rc;
-        ncclResult_t e = r->AllReduce(c->delta, c->pack, n, ncclFloat32, ncclSum, (ncclComm_t)c->comm, c->stream);
-        if (e != ncclSuccess) return rccl_fail(c, "ncclAllReduce", e);
+        if (int rc = ensure_pack(c, n + DELTA_SLACK)) return rc;
+        if (int rc = exchange(c->delta, c->pack, n)) return rc;
         k_delta_add<<<2048, WG, 0, c->stream>>>(c->w, c->w0, c->pack, c->knob.delta_accum ? c->delta : nullptr, n, 0);
     }
     return launched(c, "g2048_allreduce_deltas");

@@ -505,12 +505,16 @@ def main():
     ap.add_argument('--comm', default='native', choices=['native', 'torch'],
                     help='delta all-reduce: native = g2048_allreduce_deltas (RCCL on the engine stream; falls back to torch if it '
                          'cannot be set up), torch = torch.distributed all_reduce')
+    ap.add_argument('--comm-algo', default='', choices=['', 'allreduce', 'rsag'],
+                    help='native exchange: one ncclAllReduce (default) or ncclReduceScatter + ncclAllGather (G2048_COMM_ALGO=rsag: all xGMI links busy by construction)')
     ap.add_argument('--deadline', type=float, default=900.0,
                     help='self-launched N > 1 runs: seconds after which the parent terminates every rank and fails')
     ap.add_argument('--fault-inject', default='', help=argparse.SUPPRESS)
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend for control traffic (nccl = RCCL; gloo to rehearse on one GPU)')
     args = ap.parse_args()
 
+    if args.comm_algo:
+        os.environ['G2048_COMM_ALGO'] = args.comm_algo          # (read by g2048_create; inherited by self-launched ranks)
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         return self_launch(args)
 
@@ -624,7 +628,7 @@ def main():
         payload = eng.slots * 4 * (2 if args.rule == 'mean' else 1)
         seen = sync.info() if isinstance(sync, par.NativeSync) else (dist.get_rank(), dist.get_world_size())
         link = 153e9                                       # one xGMI link, MI355X_MICROARCH.md
-        comm = {'kind': comm_kind, 'rank_seen': seen[0], 'nranks_seen': seen[1], 'nranks_expected': world,
+        comm = {'kind': comm_kind + (' as ncclReduceScatter + ncclAllGather' if os.environ.get('G2048_COMM_ALGO') == 'rsag' and 'native' in comm_kind else ''), 'rank_seen': seen[0], 'nranks_seen': seen[1], 'nranks_expected': world,
                 'payload_bytes': payload, 'epoch_steps': args.epoch, 'exchanges_per_timed_region': -(-K // args.epoch),
                 'allreduce_plus_apply_ms': statistics.median(xs), 'allreduce_plus_apply_ms_repeats': xs,
                 'predicted_allreduce_ms': {'ring_one_link': 2 * (world - 1) / world * payload / link * 1e3,

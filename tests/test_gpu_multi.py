@@ -40,12 +40,16 @@ def test_weights_init_matches_spec(n):
     eng.close()
 
 
-@pytest.mark.parametrize('n,rule', [(4, 0), (5, 1), (3, 0), (2, 1), (6, 0)])
-def test_accumulated_delta_and_native_allreduce_world1(n, rule):
+@pytest.mark.parametrize('n,rule,algo', [(4, 0, ''), (5, 1, ''), (3, 0, ''), (2, 1, ''), (6, 0, ''), (5, 0, 'rsag'), (4, 1, 'rsag'), (3, 0, 'rsag')])
+def test_accumulated_delta_and_native_allreduce_world1(n, rule, algo, monkeypatch):
     """With one rank the epoch exchange must be the identity up to one fp32 rounding per slot: an engine that tracks its
     delta steps exactly like a plain engine (the accumulator only mirrors the adds), the accumulated delta is W - W0, and
-    g2048_allreduce_deltas through RCCL (g2048_comm_init with nranks = 1) leaves W = W0 + D."""
+    g2048_allreduce_deltas through RCCL (g2048_comm_init with nranks = 1) leaves W = W0 + D.
+    algo 'rsag' (G2048_COMM_ALGO, round 4): the same exchange as ncclReduceScatter + ncclAllGather over padded chunks (n = 3's
+    212 992 and n = 5's 5 308 416 slots are not multiples of the 256-float chunk granule times every rank count)."""
     import torch
+    if algo:
+        monkeypatch.setenv('G2048_COMM_ALGO', algo)             # (read at g2048_create)
     B, E = 8192, 6
     alpha = 0.25 if rule else 0.25 * pkg.engine.NUM_FEAT[n] / (8.0 * B)
     w_init = formulas.weights(n, scale=2.0 ** -4)
