@@ -98,6 +98,10 @@ def test_batched_td_ragged_and_to_the_end():
     gp.test_td_batch_until_all_games_end(1)
 
 
+def test_lookahead_steps_depth_zero():
+    gp.test_lookahead_steps_at_depth_zero_are_the_greedy_steps(4)
+
+
 def test_whole_game_fp32_model_and_switches():
     gp.test_td_whole_game_fp32_model_bit_exact(1)
     gp.test_td_whole_game_fp32_model_bit_exact(0)

@@ -562,6 +562,40 @@ def test_td_config4_full_size_owner_path(n):
     eng.close()
 
 
+@pytest.mark.parametrize('n', [2, 4, 6])
+def test_lookahead_steps_at_depth_zero_are_the_greedy_steps(n):
+    """g2048_lookahead_steps (csrc/lookahead.hip: roots -> tree -> k_la_pick) with depth 0 is Game.trial_run's greedy loop, and so is
+    g2048_td_steps with alpha = 0 (k_td_play): two contexts with the same lanes must play the same games — boards, scores, RNG
+    streams, statistics, what every lane did last — through two independent sets of kernels.  And a deeper search still only makes
+    legal moves: every live lane moves once per step."""
+    B = 3000
+    a, b = Engine(B, n=n, seed=77), Engine(B, n=n, seed=77)
+    w = formulas.weights(n, scale=2.0 ** -5)
+    for eng in (a, b):
+        eng.set_weights(w)
+        eng.set_auto_reset(False)
+    for _ in range(3):
+        a.td_steps(0.0, 25)
+        b.lookahead_steps(0, 1, 0, 0, 25)
+        assert np.array_equal(a.get_boards(), b.get_boards()) and np.array_equal(a.get_scores(), b.get_scores())
+        assert np.array_equal(a.get_rng(), b.get_rng()) and np.array_equal(a.last_move(), b.last_move())
+        sa, sb = a.stats(), b.stats()
+        assert (sa['moves'], sa['episodes'], sa['score_sum'], sa['valid_dirs'], sa['max_tile']) == (sb['moves'], sb['episodes'], sb['score_sum'], sb['valid_dirs'], sb['max_tile'])
+    assert np.array_equal(a.get_weights(), w) and np.array_equal(b.get_weights(), w)      # nothing was learned
+    live = int(((b.get_carry()[2] & 2) == 0).sum())
+    moves0 = b.stats()['moves']
+    b.lookahead_steps(2, 2, 8, 0, 1)
+    assert b.stats()['moves'] - moves0 == live
+    # a tile limit ends games that are not over (game_logic.py:177): with limit 2^5 every lane stops at once
+    c = Engine(64, n=n, seed=3)
+    c.set_weights(w)
+    c.set_auto_reset(False)
+    c.lookahead_steps(1, 2, 16, 5, 400)
+    assert c.stats()['episodes'] == 64 and (c.get_boards().reshape(64, 16).max(axis=1) >= 5).sum() >= 60
+    for eng in (a, b, c):
+        eng.close()
+
+
 @pytest.mark.parametrize('n', [3, 5, 6])
 def test_td_rule_and_mode_switches_mid_run(n):
     """Switching between the sum and the mean rule, and between the two update kernels, between steps: the orbit tables
