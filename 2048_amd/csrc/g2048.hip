@@ -880,36 +880,37 @@ __global__ __launch_bounds__(OWN_WG) void k_td_update_tail(float* D, TdRecs recs
 // The two f_6 orbit tables (2 x 14^6 = 15 059 072 slots of D behind the LDS-owned ones) take 8 + 4 adds per record.
 // k_td_update_tail sends them to memory as scattered atomics (~16 G/s: 0.75 ms per step of 2^20 lanes).  Here they are
 // first BINNED by table chunk and then summed by a workgroup that owns the chunk in LDS, like the other orbits:
-//   k_hex_count    every record's 12 chunk numbers -> chunk histogram (LDS per workgroup, then global)
-//   k_hex_plan     exclusive scan -> where each chunk's (slot, dw) pairs start; a work list of (chunk, part) for the owners
-//   k_hex_scatter  the same traversal; a workgroup reserves room for its tile's pairs with ONE atomic per chunk it touches,
-//                  places each pair with an LDS counter, and writes (slot, dw) — 8 B — into the chunk's run
+//   k_hex_scatter  every tile of 1 024 records: the records' 16 (slot, dw) pairs, counted per chunk in LDS; room for the tile's
+//                  share of a chunk's run reserved with ONE atomic per chunk it touches; the pairs put in chunk order in LDS and
+//                  copied out coalesced
+//   k_hex_plan     how many pairs every chunk got -> a work list of (chunk, part) for the owners; and the NEXT step's layout
 //   k_hex_owner    one workgroup per (chunk, part): pairs -> 64-bit fixed-point LDS sums (counts packed under them for the
 //                  mean rule) -> D (one writer per slot unless the chunk was split)
+// Round 4: there is no counting pass any more (round 3 ran the slot computation twice: k_hex_count, 26 us, VALU-bound).  The
+// runs of step t are laid out from what the chunks received in step t - 1 — cap = demand x 1.25 + 1 024 pairs, the board
+// distribution moves slowly — and a pair that finds its chunk's run full is added to D with a global atomic on the spot
+// (young, synchronised boards, whose distribution does move fast, pay that for their first steps; the sums are the same).
 // k_apply_orbits then moves D into the twelve member tables as before.
 constexpr uint32_t HEX_SLOTS = 2u * HEX_SIZE;               // both orbit tables, contiguous in D
 constexpr uint32_t HEX_CHUNK = 16384u;                      // slots per chunk: 128 KB of 64-bit LDS sums
 constexpr uint32_t HEX_BINS = (HEX_SLOTS + HEX_CHUNK - 1) / HEX_CHUNK;     // 920
 constexpr uint32_t HEX_PART_PAIRS = 1u << 16;               // an owner workgroup takes at most this many pairs
-// Round 4: a chunk's run is filled through EIGHT cursors, one per group of record tiles (tile % 8).  A fresh agent's pairs sit in
-// a handful of chunks, and every tile of 1 024 records reserved its share of such a chunk with a returning atomic on ONE
-// cursor: 1 024 same-address returning atomics complete one after the other (~50 ns each, see k_td_play's block counters) —
-// the 64 us of k_hex_scatter.  k_hex_count counts per (chunk, group) — a workgroup's tiles all belong to one group — so the
-// eight sub-runs are exact and lie back to back: the owners still see one contiguous run per chunk.
-constexpr uint32_t HEX_GROUPS = 8;
 constexpr uint32_t HEX_MAX_WORK = 4096;
+constexpr uint32_t HEX_YOUNG_STEPS = 64;        // TD steps after a (re)start that count their pairs before they place them (k_hex_count)
 
 struct HexWork {        // one owner workgroup
     uint32_t bin, first, count, split;      // pairs [first, first + count) of chunk `bin`; split: the chunk has several workgroups
 };
 
 struct HexBufs {
-    uint32_t* count;        // [HEX_BINS][HEX_GROUPS] pairs per chunk and tile group (this step)
-    uint32_t* base;         // [HEX_BINS + 1] first pair of each chunk
-    uint32_t* cursor;       // [HEX_BINS][HEX_GROUPS] next free pair of each (chunk, group) sub-run during the scatter
+    uint32_t* count;        // [HEX_BINS] capacity of each chunk's run (this step)
+    uint32_t* base;         // [HEX_BINS + 1] first pair of each chunk's run
+    uint32_t* cursor;       // [HEX_BINS] next free pair of each run during the scatter (may pass the run's end: what did went to D as atomics)
     uint2* pairs;           // (slot in the two tables, dw bits)
     HexWork* work;          // [HEX_MAX_WORK]
     uint32_t* nwork;
+    uint32_t* touched;      // [HEX_BINS] pairs the chunk was sent this step (0: k_hex_apply skips it)
+    uint32_t pairs_cap;     // entries of `pairs`
 };
 
 // the 16 slots (relative to the first f_6 orbit table) one record adds to: all 8 images of the corner-block representative
@@ -944,8 +945,25 @@ __device__ __forceinline__ bool hex_load_record(const TdRecs& recs, uint32_t B, 
     return true;
 }
 
+// the first layout of a context: equal runs (nothing is known yet; what does not fit goes to D as atomics)
+__global__ __launch_bounds__(OWN_WG) void k_hex_layout_init(HexBufs hb) {
+    const uint32_t j = threadIdx.x, per = hb.pairs_cap / HEX_BINS;
+    if (j < HEX_BINS) {
+        hb.count[j] = per;
+        hb.base[j] = j * per;
+        hb.cursor[j] = j * per;
+        hb.touched[j] = 0;
+    }
+    if (j == 0) hb.base[HEX_BINS] = HEX_BINS * per;
+}
+
+// YOUNG BOARDS.  For the first steps after g2048_create / g2048_reset every lane is in its opening: a handful of chunks takes all
+// 16 x 2^20 pairs and the handful changes from step to step, so "last step's demand" predicts nothing and the pairs that find their
+// run full would go to D as same-address global atomics (measured: 88 ms for the second step of a fresh 2^20-lane context, 4.5, 2.1,
+// 0.6 ms for the next ones, back to 60 us after ~48 steps).  Those steps therefore get the exact layout round 3 always computed:
+// count every chunk's pairs first (this kernel), then lay the runs out to fit (k_hex_layout_exact).
 template <int N>
-__global__ __launch_bounds__(OWN_WG) void k_hex_count(TdRecs recs, uint32_t B, HexBufs hb) {
+__global__ __launch_bounds__(OWN_WG) void k_hex_count(TdRecs recs, uint32_t B, uint32_t* demand) {
     __shared__ uint32_t hist[HEX_BINS];
     for (uint32_t j = threadIdx.x; j < HEX_BINS; j += OWN_WG) hist[j] = 0;
     __syncthreads();
@@ -960,63 +978,72 @@ __global__ __launch_bounds__(OWN_WG) void k_hex_count(TdRecs recs, uint32_t B, H
         for (int j = 0; j < HEX_PAIRS; ++j) atomicAdd(&hist[s[j] / HEX_CHUNK], 1u);
     }
     __syncthreads();
-    // (the grid is a multiple of HEX_GROUPS: every tile of 1 024 records this workgroup saw has tile % 8 == blockIdx.x % 8)
     for (uint32_t j = threadIdx.x; j < HEX_BINS; j += OWN_WG)
-        if (hist[j]) atomicAdd(&hb.count[j * HEX_GROUPS + (blockIdx.x % HEX_GROUPS)], hist[j]);
+        if (hist[j]) atomicAdd(&demand[j], hist[j]);
 }
 
-// one workgroup: scan the histogram, cut busy chunks into parts, clear the counters for the next step.  (Round 4: the work list
-// is written by all threads — a fresh agent's pairs sit in a handful of chunks of a hundred parts each, which one thread per
-// chunk used to write one after the other.)
-__global__ __launch_bounds__(OWN_WG) void k_hex_plan(HexBufs hb) {
-    __shared__ uint32_t pre[OWN_WG], wpre[OWN_WG], cnt[OWN_WG], wtot[2][OWN_WG / 64];
+__global__ __launch_bounds__(OWN_WG) void k_hex_layout_exact(HexBufs hb, const uint32_t* demand) {
+    __shared__ uint32_t wtot[OWN_WG / 64];
     const uint32_t j = threadIdx.x, lane = j & 63u, wave = j >> 6;
-    uint32_t cg[HEX_GROUPS], c = 0;
-#pragma unroll
-    for (uint32_t g = 0; g < HEX_GROUPS; ++g) {
-        cg[g] = j < HEX_BINS ? hb.count[j * HEX_GROUPS + g] : 0u;
-        c += cg[g];
-    }
-    const uint32_t parts = (c + HEX_PART_PAIRS - 1) / HEX_PART_PAIRS;
-    // inclusive scans of the pair counts and of the part counts: inside the waves with shuffles, across them through 16 totals
-    uint32_t ic = c, ip = parts;
+    const uint32_t d = j < HEX_BINS ? demand[j] : 0u;
+    uint32_t inc = d;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t uc = (uint32_t)__shfl_up((int)ic, off), up = (uint32_t)__shfl_up((int)ip, off);
+        const uint32_t up = (uint32_t)__shfl_up((int)inc, off);
+        if (lane >= (uint32_t)off) inc += up;
+    }
+    if (lane == 63u) wtot[wave] = inc;
+    __syncthreads();
+    for (uint32_t k = 0; k < wave; ++k) inc += wtot[k];
+    if (j < HEX_BINS) {
+        hb.count[j] = d;
+        hb.base[j] = inc - d;
+        hb.cursor[j] = inc - d;
+        if (j == HEX_BINS - 1) hb.base[HEX_BINS] = inc;
+    }
+}
+
+// one workgroup, behind the scatter: what every chunk received -> the owners' work list (busy chunks cut into parts) -> the next
+// step's layout.  Three inclusive scans side by side (parts, next capacities, plain demands): shuffles inside the waves, 16 totals
+// across them.
+__global__ __launch_bounds__(OWN_WG) void k_hex_plan(HexBufs hb) {
+    __shared__ uint32_t wpre[OWN_WG], cnt[OWN_WG], first_of[OWN_WG], wtot[3][OWN_WG / 64];
+    const uint32_t j = threadIdx.x, lane = j & 63u, wave = j >> 6;
+    const uint32_t base = j < HEX_BINS ? hb.base[j] : 0u, cap = j < HEX_BINS ? hb.count[j] : 0u;
+    const uint32_t demand = j < HEX_BINS ? hb.cursor[j] - base : 0u, stored = demand < cap ? demand : cap;
+    const uint32_t parts = (stored + HEX_PART_PAIRS - 1) / HEX_PART_PAIRS;
+    const uint32_t want = j < HEX_BINS ? demand + demand / 4u + 1024u : 0u;
+    uint32_t ip = parts, iw = want, id = demand;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)ip, off), uw = (uint32_t)__shfl_up((int)iw, off), ud = (uint32_t)__shfl_up((int)id, off);
         if (lane >= (uint32_t)off) {
-            ic += uc;
             ip += up;
+            iw += uw;
+            id += ud;
         }
     }
     if (lane == 63u) {
-        wtot[0][wave] = ic;
-        wtot[1][wave] = ip;
+        wtot[0][wave] = ip;
+        wtot[1][wave] = iw;
+        wtot[2][wave] = id;
     }
     __syncthreads();
-    for (uint32_t k = 0; k < wave; ++k) {
-        ic += wtot[0][k];
-        ip += wtot[1][k];
-    }
-    pre[j] = ic;
-    wpre[j] = ip;
-    cnt[j] = c;
-    __syncthreads();
-    const uint32_t first = pre[j] - c;
-    if (j < HEX_BINS) {
-        hb.base[j] = first;
-        uint32_t at = first;
-#pragma unroll
-        for (uint32_t g = 0; g < HEX_GROUPS; ++g) {         // the chunk's eight sub-runs, back to back
-            hb.cursor[j * HEX_GROUPS + g] = at;
-            hb.count[j * HEX_GROUPS + g] = 0;
-            at += cg[g];
+    uint32_t all_want = 0;
+    for (uint32_t k = 0; k < OWN_WG / 64; ++k) {
+        if (k < wave) {
+            ip += wtot[0][k];
+            iw += wtot[1][k];
+            id += wtot[2][k];
         }
+        all_want += wtot[1][k];
     }
+    wpre[j] = ip;
+    cnt[j] = stored;
+    first_of[j] = base;
+    __syncthreads();
     const uint32_t nwork = wpre[OWN_WG - 1] < HEX_MAX_WORK ? wpre[OWN_WG - 1] : HEX_MAX_WORK;
-    if (j == OWN_WG - 1) {
-        hb.base[HEX_BINS] = pre[j];
-        *hb.nwork = nwork;
-    }
+    if (j == 0) *hb.nwork = nwork;
     // work item w belongs to the chunk whose inclusive part count first exceeds w
     for (uint32_t w = j; w < nwork; w += OWN_WG) {
         uint32_t lo = 0, hi = OWN_WG - 1;
@@ -1027,9 +1054,19 @@ __global__ __launch_bounds__(OWN_WG) void k_hex_plan(HexBufs hb) {
             else
                 lo = mid + 1;
         }
-        const uint32_t bin = lo, cb = cnt[bin], pb = (cb + HEX_PART_PAIRS - 1) / HEX_PART_PAIRS, k = w - (wpre[bin] - pb), fb = pre[bin] - cb;
+        const uint32_t bin = lo, cb = cnt[bin], pb = (cb + HEX_PART_PAIRS - 1) / HEX_PART_PAIRS, k = w - (wpre[bin] - pb);
         const uint32_t plo = (uint32_t)((uint64_t)cb * k / pb), phi = (uint32_t)((uint64_t)cb * (k + 1) / pb);
-        hb.work[w] = HexWork{bin, fb + plo, phi - plo, pb > 1 ? 1u : 0u};
+        hb.work[w] = HexWork{bin, first_of[bin] + plo, phi - plo, pb > 1 ? 1u : 0u};
+    }
+    // the next step's runs: room for a quarter more than this step's demand (if that does not fit, for exactly the demand)
+    const bool roomy = all_want <= hb.pairs_cap;
+    if (j < HEX_BINS) {
+        const uint32_t next_cap = roomy ? want : demand, next_base = roomy ? iw - want : id - demand;
+        hb.touched[j] = demand;
+        hb.count[j] = next_cap;
+        hb.base[j] = next_base;
+        hb.cursor[j] = next_base;
+        if (j == HEX_BINS - 1) hb.base[HEX_BINS] = next_base + next_cap;
     }
 }
 
@@ -1038,9 +1075,10 @@ __global__ __launch_bounds__(OWN_WG) void k_hex_plan(HexBufs hb) {
 // it — sixteen 8-byte stores per lane into sixteen different runs, 15.3 M separate L1 accesses per launch with the L1 busy 90 % of
 // the kernel's 64 us (TCP_TOTAL_CACHE_ACCESSES / TCP_GATE_EN1, profiles/r04_pmc_summary.json): a request-rate bound like k_td_play's.
 template <int N>
-__global__ __launch_bounds__(OWN_WG) void k_hex_scatter(TdRecs recs, uint32_t B, HexBufs hb) {
+__global__ __launch_bounds__(OWN_WG) void k_hex_scatter(TdRecs recs, uint32_t B, HexBufs hb, float* D, float* Dc) {
     __shared__ uint2 stage[OWN_WG * HEX_PAIRS];
-    __shared__ uint32_t hist[HEX_BINS], lofs[HEX_BINS], lbase[HEX_BINS], wtot[OWN_WG / 64];
+    __shared__ uint32_t hist[HEX_BINS], lofs[HEX_BINS], lbase[HEX_BINS], lend[HEX_BINS], wtot[OWN_WG / 64];
+    for (uint32_t j = threadIdx.x; j < HEX_BINS; j += OWN_WG) lend[j] = hb.base[j] + hb.count[j];      // where each chunk's run ends
     const uint32_t total = B + *recs.qcount;
     const uint32_t ntiles = (total + OWN_WG - 1) / OWN_WG;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -1057,7 +1095,7 @@ __global__ __launch_bounds__(OWN_WG) void k_hex_scatter(TdRecs recs, uint32_t B,
             for (int j = 0; j < HEX_PAIRS; ++j) rank[j] = atomicAdd(&hist[s[j] / HEX_CHUNK], 1u);      // place inside the tile's share of the chunk
         }
         __syncthreads();
-        // one thread per chunk: room in the chunk's run (its group's cursor), and the chunk's offset in the staging area (an
+        // one thread per chunk: room in the chunk's run, and the chunk's offset in the staging area (an
         // exclusive scan of the histogram: wave scans + the 16 wave totals)
         const uint32_t h = threadIdx.x < HEX_BINS ? hist[threadIdx.x] : 0u;
         uint32_t inc = h;
@@ -1067,7 +1105,7 @@ __global__ __launch_bounds__(OWN_WG) void k_hex_scatter(TdRecs recs, uint32_t B,
             if (lane >= (uint32_t)off) inc += up;
         }
         if (lane == 63u) wtot[wave] = inc;
-        if (threadIdx.x < HEX_BINS) lbase[threadIdx.x] = h ? atomicAdd(&hb.cursor[threadIdx.x * HEX_GROUPS + (tile % HEX_GROUPS)], h) : 0u;
+        if (threadIdx.x < HEX_BINS) lbase[threadIdx.x] = h ? atomicAdd(&hb.cursor[threadIdx.x], h) : 0u;
         __syncthreads();
         uint32_t before = 0;
         for (uint32_t k = 0; k < wave; ++k) before += wtot[k];
@@ -1083,8 +1121,13 @@ __global__ __launch_bounds__(OWN_WG) void k_hex_scatter(TdRecs recs, uint32_t B,
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < npairs; i += OWN_WG) {
             const uint2 pr = stage[i];
-            const uint32_t bin = pr.x / HEX_CHUNK;
-            hb.pairs[lbase[bin] + (i - lofs[bin])] = pr;
+            const uint32_t bin = pr.x / HEX_CHUNK, pos = lbase[bin] + (i - lofs[bin]);
+            if (pos < lend[bin]) {
+                hb.pairs[pos] = pr;
+            } else {                        // the run is full (the chunk got more than 1.25 x last step's pairs): straight to D
+                __hip_atomic_fetch_add(&D[pr.x], __uint_as_float(pr.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (Dc) __hip_atomic_fetch_add(&Dc[pr.x], 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
         __syncthreads();
     }
@@ -1143,7 +1186,7 @@ __global__ __launch_bounds__(OWN_WG) void k_hex_owner(float* D, float* Dc, const
 __global__ __launch_bounds__(WG) void k_hex_apply(float* w, float* dacc, float* Dh, float* Ch, HexBufs hb, OrbitInfo oa, OrbitInfo ob) {
     const uint32_t K = blockIdx.x * WG + threadIdx.x;           // (a workgroup's 256 slots lie in one chunk)
     const uint32_t bin = K / HEX_CHUNK;
-    if (K >= HEX_SLOTS || hb.base[bin + 1] == hb.base[bin]) return;
+    if (K >= HEX_SLOTS || hb.touched[bin] == 0) return;
     float v = Dh[K];
     if (Ch) {
         const float cnt = Ch[K];
@@ -1458,7 +1501,8 @@ struct g2048_ctx {
     bool tracking = false;
     float* pack = nullptr;
     size_t pack_count = 0;
-    HexBufs hex = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // n = 6: binned update of the f_6 orbits (k_hex_*)
+    uint32_t hex_young = 0;             // TD steps left with the exact layout of the f_6 bins (k_hex_count: young, synchronised boards)
+    HexBufs hex = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};   // n = 6: binned update of the f_6 orbits (k_hex_*)
     void* comm = nullptr;               // ncclComm_t of g2048_comm_init
     int comm_rank = 0, comm_ranks = 1;
     Stats* stats = nullptr;
@@ -1931,11 +1975,13 @@ int build_slices(g2048_ctx* c) {
             if ((rc = dalloc(c, &c->D2, c->owned_total))) return rc;
             HIP_TRY(c, hipMemset(c->D2, 0, (size_t)c->owned_total * 4));
             if (c->n == 6 && c->B <= (1u << 23)) {       // binned update of the f_6 orbits: 16 pairs per record, main + terminal
-                if ((rc = dalloc(c, &c->hex.count, HEX_BINS * HEX_GROUPS)) || (rc = dalloc(c, &c->hex.base, HEX_BINS + 1)) ||
-                    (rc = dalloc(c, &c->hex.cursor, HEX_BINS * HEX_GROUPS)) || (rc = dalloc(c, &c->hex.pairs, (size_t)2 * HEX_PAIRS * c->B)) ||
-                    (rc = dalloc(c, &c->hex.work, HEX_MAX_WORK)) || (rc = dalloc(c, &c->hex.nwork, 1)))
+                c->hex.pairs_cap = (uint32_t)std::min<uint64_t>((uint64_t)2 * HEX_PAIRS * c->B + 2048ull * HEX_BINS, 0xFFFFFFFFull);
+                if ((rc = dalloc(c, &c->hex.count, HEX_BINS)) || (rc = dalloc(c, &c->hex.base, HEX_BINS + 1)) ||
+                    (rc = dalloc(c, &c->hex.cursor, HEX_BINS)) || (rc = dalloc(c, &c->hex.pairs, (size_t)c->hex.pairs_cap)) ||
+                    (rc = dalloc(c, &c->hex.work, HEX_MAX_WORK)) || (rc = dalloc(c, &c->hex.nwork, 1)) || (rc = dalloc(c, &c->hex.touched, HEX_BINS)))
                     return rc;
-                HIP_TRY(c, hipMemset(c->hex.count, 0, HEX_BINS * HEX_GROUPS * 4));
+                k_hex_layout_init<<<1, OWN_WG, 0, c->stream>>>(c->hex);
+                c->hex_young = HEX_YOUNG_STEPS;
             }
         }
         if (int rc = dalloc(c, &c->slices, MAX_SLICES)) return rc;
@@ -2378,9 +2424,14 @@ int launch_td_step(g2048_ctx* c, float alpha, hipEvent_t ev = nullptr, hipEvent_
         if (hex_binned) {           // the f_6 orbits: bin the (slot, dw) pairs by table chunk, then LDS owners (k_hex_*)
             const uint32_t hb = c->orbits.o[6].base;
             const unsigned owners = (unsigned)std::min<uint64_t>(HEX_MAX_WORK, HEX_BINS + (uint64_t)2 * HEX_PAIRS * B / HEX_PART_PAIRS + 1);
-            k_hex_count<6><<<512, OWN_WG, 0, c->stream>>>(recs, B, c->hex);
+            if (c->hex_young) {         // the opening of 2^20 synchronised games: exact runs (k_hex_count), see there
+                --c->hex_young;
+                HIP_TRY(c, hipMemsetAsync(c->hex.touched, 0, HEX_BINS * sizeof(uint32_t), c->stream));
+                k_hex_count<6><<<512, OWN_WG, 0, c->stream>>>(recs, B, c->hex.touched);
+                k_hex_layout_exact<<<1, OWN_WG, 0, c->stream>>>(c->hex, c->hex.touched);
+            }
+            k_hex_scatter<6><<<1024, OWN_WG, 0, c->stream>>>(recs, B, c->hex, c->D + hb, c->update_rule == 1 ? c->Dcnt + hb : nullptr);
             k_hex_plan<<<1, OWN_WG, 0, c->stream>>>(c->hex);
-            k_hex_scatter<6><<<1024, OWN_WG, 0, c->stream>>>(recs, B, c->hex);
             k_hex_owner<<<owners, OWN_WG, 0, c->stream>>>(c->D + hb, c->update_rule == 1 ? c->Dcnt + hb : nullptr, recs, c->hex);
         } else if (c->n == 6) {
             k_td_update_tail<6><<<tail_grid, OWN_WG, 0, c->stream>>>(c->D, recs, B, c->orbits.o[6].base, c->orbits.o[7].base);
@@ -2488,7 +2539,7 @@ int g2048_destroy(g2048_ctx* c) {
                     c->qdw,    c->qcount, c->last_move, c->w,      c->w0,  c->delta,   c->stats,   c->scratch, c->slices, c->statbuf, c->D, c->Dcnt, c->D2, c->Dcnt2, c->pack, c->lane_id,
                     c->alt.boards, c->alt.scores, c->alt.rng, c->alt.label, c->alt.flags, c->alt.lane_id, c->alt.last_move,
                     c->sort_key16, c->sort_off, c->sort_perm, c->sort_cnt, c->sort_start,
-                    c->hex.count, c->hex.base, c->hex.cursor, c->hex.pairs, c->hex.work, c->hex.nwork};
+                    c->hex.count, c->hex.base, c->hex.cursor, c->hex.pairs, c->hex.work, c->hex.nwork, c->hex.touched};
     for (void* p : bufs)
         if (p && (p != (void*)c->w || c->owns_table)) (void)hipFree(p);
     if (c->la_ws) (void)hipFree(c->la_ws);
@@ -2666,6 +2717,7 @@ int g2048_reset(g2048_ctx* c) {
     if (int rc = bind(c)) return rc;
     NEED_IDENTITY(c);
     c->replan_interval = 1;         // the tile distribution restarts: follow it closely again
+    c->hex_young = HEX_YOUNG_STEPS;
     k_new_games<<<grid_for(c->B), WG, 0, c->stream>>>(c->boards, c->scores, c->rng, c->label, c->flags, c->B);
     if (c->log.lanes) k_log_init<<<grid_for(c->log.lanes), WG, 0, c->stream>>>(c->log, c->boards, c->flags);
     return launched(c, "k_new_games");
