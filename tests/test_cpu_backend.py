@@ -131,6 +131,7 @@ def test_surface_trial_reproduces_the_reference_trial(api, golden, tmp_path):
 def test_surface_look_forward_and_reference_pickles(api, golden, tmp_path, monkeypatch):
     gs.test_look_forward_matches_reference_fixture(api, golden)
     gs.test_device_look_forward_matches_the_reference(golden)
+    gs.test_game_find_best_move_with_depth_goes_through_the_device_look_ahead(api, golden, monkeypatch)
     gs.test_trial_with_lookahead_reproduces_the_reference_trial(api, golden)
     gs.test_reference_written_pickles_load(api, golden, tmp_path, monkeypatch)
     gs.test_device_game_records(api)

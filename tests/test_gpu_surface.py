@@ -281,6 +281,36 @@ def test_trial_with_lookahead_reproduces_the_reference_trial(api, golden):
         assert [(t, p[0] * 4 + p[1]) for t, p in r.tiles] == [tuple(x) for x in g['tiles'][i, :k].tolist()]
 
 
+def test_game_find_best_move_with_depth_goes_through_the_device_look_ahead(api, golden, monkeypatch):
+    """Game._find_best_move(depth > 0) with a device agent's `evaluate` as estimator (what show.py's watch mode and trial_run call,
+    game_logic.py:150-161): the candidates' trees go through g2048_boards_look_forward with a salt drawn from `random`.  With the
+    salt pinned to zero the chosen move must be the first maximum of the fixture's values for the four afterstates — i.e. the
+    reference's own _find_best_move on the same chance nodes (lookahead_dev.npz)."""
+    g = golden('lookahead_dev.npz')
+    n = 3
+    agent = api.QAgent(name='t', storage='local', console='local', n=n, with_weights=False)
+    sizes = formulas.feature_sizes(n)
+    flat = formulas.weights(n, scale=float(g[f'scale_n{n}'])).astype(np.float32)
+    offs = np.concatenate([[0], np.cumsum(sizes)[:-1]])
+    agent.weights = [flat[o:o + s] for o, s in zip(offs, sizes)]
+    import random
+    monkeypatch.setattr(random, 'getrandbits', lambda k: 0)
+    for ci, (depth, width, since_empty) in enumerate(g['configs'][:4]):
+        for bi in range(0, len(g['boards']), 4):
+            game = api.Game(row=g['boards'][bi].astype(np.int32))
+            best_dir, best_row, best_score = game._find_best_move(agent.evaluate, int(depth), int(width), int(since_empty))
+            assert best_dir == g[f'best_dir_n{n}'][0, ci, bi], (ci, bi)
+            row, score, changed = game.pre_move(game.row, game.score, best_dir)
+            if best_row is None:                                # (the fixture's first board is empty: no direction changes it, :151-152)
+                assert not any(game.pre_move(game.row, 0, d)[2] for d in range(4))
+            else:
+                assert changed and np.array_equal(row, best_row) and score == best_score
+    # and the generator show.py's watch mode iterates (game_logic.py:203-211) runs with it
+    game = api.Game()
+    steps = list(zip(range(6), game.generate_run(agent.evaluate, depth=1, width=2, since_empty=16)))
+    assert len(steps) == 6 and game.odometer == 5 and all(d in (0, 1, 2, 3) for _, (_, d) in steps)
+
+
 def test_trial_with_lookahead_plays_all_games_in_one_batch(api):
     """depth > 0 (game_logic.py:214-243 under trial_run): all games' trees go through lookahead.expectimax_values together.
     Every returned Game is a full record that replays to its final position; looking ahead does not play worse than greedy
