@@ -251,3 +251,20 @@ def test_bench_eight_ranks_rank_killed_and_deadline():
     res, line, dt = _bench_cpu('--comm', 'torch', '--fault-inject', 'hang@3:init,hang@6:init', '--deadline', '25', gpus=8, batch=512, threads=1)
     assert res.returncode != 0 and line is None and 20 < dt < 120
     assert '--deadline 25 s passed' in res.stderr and res.stdout.strip() == ''
+
+
+def test_bench_side_workloads_run_on_the_cpu_backend():
+    """`bench.py --workload env | eval | lookahead` (BASELINE configs 2, 3 and the look-ahead values line) end to end on small batches."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, G2048_BACKEND='cpu', G2048_CPU_THREADS='4')
+    for workload, unit in (('env', 'board-steps/s'), ('eval', 'boards/s'), ('lookahead', 'positions/s')):
+        res = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--workload', workload, '--batch', '512', '--steps', '8', '--warmup', '8', '--n-tuple', '4'],
+                             capture_output=True, text=True, timeout=300, env=env)
+        assert res.returncode == 0, res.stderr[-1500:]
+        line = json.loads(res.stdout.strip().splitlines()[-1])
+        assert line['unit'] == unit and line['value'] > 0 and line['batch'] == 512
+        if workload == 'lookahead':
+            assert line['finite'] and line['leaf_slots_per_s'] > line['value']
