@@ -73,6 +73,52 @@ G2048_HD uint32_t cross_unorder(uint32_t o) {
     return (c4 << 16) | bit_transpose16(t);
 }
 
+// ---- the order of the FOUR-cell orbits' accumulation tables (n >= 4).  An LDS owner holds 16 384 fixed-point slots and every
+// chunk that is held costs a scan of all records, so the order wants all of a step's adds in as few chunks as possible.  Cut by
+// the index's top bits (the leading cell), young boards spread over 2 - 3 of an orbit's 4 chunks (0.75 - 0.83 / 0.16 - 0.23 /
+// 0.01 - 0.03 of the adds).  Instead the 11^4 = 14 641 indices whose four cells are all <= 10 (tiles up to 1 024) come first, as
+// base-11 numbers — chunk 0, with EVERY add of an agent that has not made a 2 048 yet and 0.70 - 0.99 of a trained one's — and
+// behind them, from slot QUAD_HOT on, the whole 16-bit index space in index order, of which only the entries with a cell >= 11 are
+// ever used (the others are holes: 5 chunks per orbit instead of 4, 80 KB of D more).  Records keep the plain 16-bit indices; the
+// owner kernel maps them, two indices per 32-bit word at a time (own_accum_quad).
+constexpr uint32_t QUAD_HOT = 16384u, QUAD_DSIZE = QUAD_HOT + 65536u, QUAD_HOT_USED = 14641u;
+G2048_HD bool quad_is_hot(uint32_t k) {          // all four nibbles of k <= 10
+    return ((k & ((k & 0x7777u) + 0x5555u)) & 0x8888u) == 0u;
+}
+G2048_HD uint32_t quad_base11(uint32_t k) { return (((k >> 12) & 15u) * 11u + ((k >> 8) & 15u)) * 121u + ((k >> 4) & 15u) * 11u + (k & 15u); }
+G2048_HD uint32_t quad_place(uint32_t k) { return quad_is_hot(k) ? quad_base11(k) : QUAD_HOT + k; }
+// the index whose place is K; false for a hole.  `plain`: no index is hot (every index lives at QUAD_HOT + k; g2048.hip, QuadOrder)
+G2048_HD bool quad_unplace(uint32_t K, uint32_t& k, bool plain = false) {
+    if (K < QUAD_HOT) {
+        if (plain || K >= QUAD_HOT_USED) return false;
+        const uint32_t c3 = K % 11u, r2 = K / 11u, c2 = r2 % 11u, r1 = r2 / 11u, c1 = r1 % 11u, c0 = r1 / 11u;
+        k = c0 << 12 | c1 << 8 | c2 << 4 | c3;
+        return true;
+    }
+    k = K - QUAD_HOT;
+    return k < 65536u && (plain || !quad_is_hot(k));
+}
+
+// The records hold the plain 16-bit indices, two per 32-bit word; both halves of a word at once: which nibbles are >= 11, and
+// the base-11 value of each half (= its place if it has no such nibble).
+G2048_HD uint32_t quad_big_nibbles(uint32_t x) { return x & ((x & 0x77777777u) + 0x55555555u) & 0x88888888u; }
+G2048_HD uint32_t quad_base11_halves(uint32_t x) {
+    const uint32_t h = (x >> 4) & 0x0F0F0F0Fu;
+    uint32_t h4 = h << 2;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // (the device compiler folds x - h - 4 h (and a b - 135 g) into 64-bit multiply-adds, v_mad_u64_u32: quarter rate.  The empty asm
+    // hides that h4 is 4 h; g < 2^24, so 121 g + lo is one full-rate 24-bit multiply-add)
+    asm volatile("" : "+v"(h4));
+#endif
+    const uint32_t b = x - h - h4;                           // every byte 16 hi + lo -> 11 hi + lo
+    const uint32_t g = (b >> 8) & 0x00FF00FFu, lo = b & 0x00FF00FFu;
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul24(g, 121u) + lo;                           // every half 256 B1 + B0 -> 121 B1 + B0 (one v_mad_u32_u24)
+#else
+    return g * 121u + lo;
+#endif
+}
+
 G2048_HD uint32_t pack16(uint32_t w) {      // bytes b0..b3 (cells 0..3 of a line) -> b0<<12|b1<<8|b2<<4|b3
     return ((w & 0xFu) << 12) | ((w >> 8 & 0xFu) << 8) | ((w >> 16 & 0xFu) << 4) | (w >> 24 & 0xFu);
 }

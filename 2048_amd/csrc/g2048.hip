@@ -277,6 +277,7 @@ struct Slice {
     uint32_t cshift;        // log2 of the slots per chunk of this orbit table (OWN_SLOTS, or OWN_SLOTS / 2 for the fixed-point orbits)
     uint32_t fixed;         // 1: this workgroup sums in 64-bit fixed point (own_fixed, or every variant under the one-pass mean rule)
     uint32_t xcd;           // 1: XCD-resident plan — part = x * (nparts / 8) + j scans the record blocks b = x + 8 * (j + (nparts / 8) * t)
+    uint32_t quad_plain;    // 1: the four-cell orbits' tables are used in index order only (no index is "hot": QuadOrder below)
 };
 
 // Symmetry orbits (n >= 4).  QAgent.update adds dw at f_i(g.x) for all 8 images g (r_learning.py:207-214).  Features
@@ -386,8 +387,31 @@ __device__ __forceinline__ long long to_fixed(float dw, double scale) {
 // One-pass mean rule (cbits > 0): the low `cbits` bits of a fixed-point slot count the adds, the rest is the sum — every
 // add is (dw * 2^S << cbits) + 1, the flush splits the word again (k_td_update_owner).  cbits = 0: sums only.
 __device__ __forceinline__ unsigned long long packed_add(float dw, double scale, uint32_t cbits) {
-    const long long fixed = to_fixed(dw, scale);
-    return ((unsigned long long)fixed << cbits) + (cbits ? 1ull : 0ull);
+    unsigned long long fixed = (unsigned long long)to_fixed(dw, scale);
+    if (cbits) fixed = (fixed << cbits) + 1ull;         // (wave-uniform: the sum rule skips the 64-bit shift and add)
+    return fixed;
+}
+
+// Fallback adds — to chunks of the orbit that no workgroup holds — first meet in a small direct-mapped {D slot, packed sum} cache
+// in the 32 KB of LDS the accumulators leave free (behind the 64 fallback hit counters of `fb_hits`): memory-side atomics
+// serialise per address, and what young boards send to a light chunk lands on a handful of its slots (a fallback share of 3 %
+// cost 70 us of global atomics per launch without this).  Only a slot that finds its cache line taken goes to D directly.
+// The words are the workgroup's own packed fixed-point adds (packed_add); the flush in k_td_update_owner splits them again.
+constexpr uint32_t FB_CACHE = 2048u, FB_EMPTY = 0xFFFFFFFFu, FB_WORDS = 64u + FB_CACHE + 2u * FB_CACHE;
+__device__ __forceinline__ uint32_t* fb_keys(uint32_t* fb_hits) { return fb_hits + 64; }
+__device__ __forceinline__ unsigned long long* fb_vals(uint32_t* fb_hits) { return reinterpret_cast<unsigned long long*>(fb_hits + 64 + FB_CACHE); }
+template <bool FIXED>
+__device__ __forceinline__ void fb_add(uint32_t* fb_hits, float* D, float* Dc, uint32_t dslot, float dw, double scale, uint32_t cbits) {
+    if (FIXED) {
+        const uint32_t h = (dslot * 2654435761u) >> 21;                 // 11 bits
+        const uint32_t prev = atomicCAS(&fb_keys(fb_hits)[h], FB_EMPTY, dslot);
+        if (prev == FB_EMPTY || prev == dslot) {
+            atomicAdd(&fb_vals(fb_hits)[h], packed_add(dw, scale, cbits));
+            return;
+        }
+    }
+    __hip_atomic_fetch_add(&D[dslot], dw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (Dc) __hip_atomic_fetch_add(&Dc[dslot], 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 template <int N, int F0, int FC, bool FB, bool FIXED, uint32_t IMAGES>
@@ -403,9 +427,10 @@ __device__ __forceinline__ void own_accum(const Packed& p, float dw, bool valid,
         feature_slots<N>(d4_image(p, g), s);         // g is a constant after unrolling; unused slots are dead code
 #pragma unroll
         for (int f = F0; f < F0 + FC; ++f) {
-            const bool cross = N >= 5 && f >= 17 && f < 21;                 // the cross orbit's table is in cross_order
-            const uint32_t orel = cross ? cross_order(s[f] - sl.orb_tlo) : 0u;
-            const uint32_t local = cross ? orel - (sl.tlo - sl.orb_tlo) : s[f] - sl.tlo;
+            const bool cross = N >= 5 && f >= 17 && f < 21;                 // the cross orbit's table is in cross_order,
+            const uint32_t rel16 = s[f] - sl.orb_tlo;                       // a four-cell orbit's in quad_place order (features.hpp)
+            const uint32_t orel = cross ? cross_order(rel16) : f < 17 ? (sl.quad_plain ? QUAD_HOT + rel16 : quad_place(rel16)) : rel16;
+            const uint32_t local = orel - (sl.tlo - sl.orb_tlo);
             const bool hit = valid && local < sl.size;
             if (hit) {
                 if (FIXED)
@@ -415,10 +440,9 @@ __device__ __forceinline__ void own_accum(const Packed& p, float dw, bool valid,
             }
             nhit += hit ? 1u : 0u;
             if (FB && valid && !hit) {
-                const uint32_t rel = cross ? orel : s[f] - sl.orb_tlo, ch = rel >> sl.cshift;
+                const uint32_t rel = orel, ch = rel >> sl.cshift;
                 if ((sl.fb_mask >> ch) & 1u) {
-                    __hip_atomic_fetch_add(&D[sl.orb_dlo + rel], dw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (Dc) __hip_atomic_fetch_add(&Dc[sl.orb_dlo + rel], 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    fb_add<FIXED>(fb_hits, D, Dc, sl.orb_dlo + rel, dw, (double)scale, cbits);
                     atomicAdd(&fb_hits[ch], 1u);            // LDS counter, flushed once per workgroup
                 }
             }
@@ -482,15 +506,57 @@ __device__ __forceinline__ void own_accum_idx(const uint32_t (&idx)[NI], float d
             if (!hit[j]) {
                 const uint32_t rel = idx[j], ch = rel >> sl.cshift;
                 if ((sl.fb_mask >> ch) & 1u) {
-                    __hip_atomic_fetch_add(&D[sl.orb_dlo + rel], dw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (Dc) __hip_atomic_fetch_add(&Dc[sl.orb_dlo + rel], 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    fb_add<FIXED>(fb_hits, D, Dc, sl.orb_dlo + rel, dw, (double)scale, cbits);
                     atomicAdd(&fb_hits[ch], 1u);            // LDS counter, flushed once per workgroup
                 }
             }
     }
 }
 
-template <int N, int V, bool FB, bool FIXED>
+// NI indices (4: words x, y; 1: the low half of x) of one record into the chunk of this workgroup: HOT = chunk 0 (all cells <= 10),
+// otherwise the chunk of the indices [lo16, lo16 + 16 384) that have a cell >= 11.
+template <int NI, bool FB, bool HOT>
+__device__ __forceinline__ void own_accum_quad(uint32_t x, uint32_t y, float dw, bool valid, float* acc, const Slice& sl, uint32_t lo16,
+                                               uint32_t& nhit_lane, float* D, float* Dc, uint32_t* fb_hits, double scale, uint32_t cbits) {
+    const uint32_t w[2] = {x, y};
+    bool hit[NI];
+    uint32_t local[NI];
+    bool any = false;
+#pragma unroll
+    for (int p = 0; p < (NI + 1) / 2; ++p) {
+        const uint32_t big = quad_big_nibbles(w[p]);
+        const uint32_t b11 = HOT ? quad_base11_halves(w[p]) : 0u;
+#pragma unroll
+        for (int h = 0; h < 2 && 2 * p + h < NI; ++h) {
+            const int j = 2 * p + h;
+            const uint32_t big_h = h ? big >> 16 : big & 0xFFFFu, idx = h ? w[p] >> 16 : w[p] & 0xFFFFu;
+            local[j] = HOT ? (h ? b11 >> 16 : b11 & 0xFFFFu) : idx - lo16;
+            hit[j] = valid && (HOT ? big_h == 0u : ((big_h != 0u || sl.quad_plain) && local[j] < QUAD_HOT));
+            any |= hit[j];
+            nhit_lane += hit[j] ? 1u : 0u;
+        }
+    }
+    if (any) {
+        const unsigned long long fixed = packed_add(dw, scale, cbits);
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+            if (hit[j]) atomicAdd(reinterpret_cast<unsigned long long*>(acc) + local[j], fixed);
+    }
+    if (FB && valid) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+            if (!hit[j]) {
+                const uint32_t idx = (j & 1) ? w[j >> 1] >> 16 : w[j >> 1] & 0xFFFFu;
+                const uint32_t rel = (HOT || sl.quad_plain) ? QUAD_HOT + idx : quad_place(idx), ch = rel >> sl.cshift;       // (a miss of chunk 0 has a cell >= 11)
+                if ((sl.fb_mask >> ch) & 1u) {
+                    fb_add<true>(fb_hits, D, Dc, sl.orb_dlo + rel, dw, scale, cbits);
+                    atomicAdd(&fb_hits[ch], 1u);
+                }
+            }
+    }
+}
+
+template <int N, int V, bool FB, bool FIXED, bool HOT>
 __device__ __forceinline__ void own_run(float* acc, const Slice& s, const TdRecs& recs, uint32_t B, uint32_t* hits, float* D, float* Dc,
                                         uint32_t* fb_hits, float scale, uint32_t cbits) {
     constexpr int F0 = OwnVariants<N>::f0(V), FC = OwnVariants<N>::fc(V);
@@ -512,7 +578,7 @@ __device__ __forceinline__ void own_run(float* acc, const Slice& s, const TdRecs
         // The loop has to stay this plain for it: a hand-out of blocks through a bit pattern cost 10 %, profiles/r03_experiments.txt item 19)
         _Pragma("unroll 2") for (uint32_t blk = first; blk < nblk; blk += stride) {
             const uint32_t base0 = blk * BLK;
-            uint32_t idx[U][NI];
+            uint32_t idx[U][NI];            // (V < 5: the record's index words as stored, idx[u][0 .. 1])
             float dw[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -521,7 +587,7 @@ __device__ __forceinline__ void own_run(float* acc, const Slice& s, const TdRecs
                 const uint32_t rr = ok ? r : end - 1;
                 if constexpr (V < 4) {
                     const uint2 t = oi.q[(size_t)V * B + rr];
-                    idx[u][0] = t.x & 0xFFFFu; idx[u][1] = t.x >> 16; idx[u][2] = t.y & 0xFFFFu; idx[u][3] = t.y >> 16;
+                    idx[u][0] = t.x; idx[u][1] = t.y;
                 } else if constexpr (V == 4) {
                     idx[u][0] = oi.c[rr];
                 } else {
@@ -533,8 +599,15 @@ __device__ __forceinline__ void own_run(float* acc, const Slice& s, const TdRecs
                 if (recs.unit) dw[u] = dw[u] != 0.0f ? 1.0f : 0.0f;
             }
 #pragma unroll
-            for (int u = 0; u < U; ++u)
-                own_accum_idx<NI, FB, FIXED>(idx[u], dw[u], dw[u] != 0.0f, acc, s, lo_rel, nhit_wave, D, Dc, fb_hits, (double)scale, cbits);
+            for (int u = 0; u < U; ++u) {
+                if constexpr (V < 5) {
+                    static_assert(V >= 5 || FIXED, "the four-cell orbits sum in fixed point (chunks of QUAD_HOT slots)");
+                    own_accum_quad<NI, FB, HOT>(idx[u][0], idx[u][NI > 1 ? 1 : 0], dw[u], dw[u] != 0.0f, acc, s, lo_rel - QUAD_HOT, nhit_wave, D, Dc,
+                                                fb_hits, (double)scale, cbits);
+                } else {
+                    own_accum_idx<NI, FB, FIXED>(idx[u], dw[u], dw[u] != 0.0f, acc, s, lo_rel, nhit_wave, D, Dc, fb_hits, (double)scale, cbits);
+                }
+            }
         }
     } else {   // main records: this part's share of the lanes, OWN_UNROLL records per thread in flight; the loop bounds are
         // wave-uniform
@@ -588,16 +661,29 @@ __device__ __forceinline__ void own_dispatch(float* acc, const Slice& s, const T
             // instantiations keep its tests out of everybody else's inner loop.  A variant that own_fixed leaves in fp32
             // (the cross orbit) also exists in fixed point: the one-pass mean rule needs the packed counts.
             const bool fb = N >= 4 && s.fb_mask;
-            if (own_fixed(N, V) || s.fixed) {
+            if constexpr (N >= 4 && V < 5) {       // a four-cell orbit: chunk 0 (all cells <= 10) or one of the four behind it
+                static_assert(own_fixed(N, V) && FIXED_SLOTS == QUAD_HOT, "four-cell orbits: fixed point, chunks of QUAD_HOT slots");
+                if (s.tlo == s.orb_tlo && !s.quad_plain) {
+                    if (fb)
+                        own_run<N, V, true, true, true>(acc, s, recs, B, hits, D, Dc, fb_hits, scale, cbits);
+                    else
+                        own_run<N, V, false, true, true>(acc, s, recs, B, hits, D, Dc, fb_hits, scale, cbits);
+                } else {
+                    if (fb)
+                        own_run<N, V, true, true, false>(acc, s, recs, B, hits, D, Dc, fb_hits, scale, cbits);
+                    else
+                        own_run<N, V, false, true, false>(acc, s, recs, B, hits, D, Dc, fb_hits, scale, cbits);
+                }
+            } else if (own_fixed(N, V) || s.fixed) {
                 if (fb)
-                    own_run<N, V, true, true>(acc, s, recs, B, hits, D, Dc, fb_hits, scale, cbits);
+                    own_run<N, V, true, true, false>(acc, s, recs, B, hits, D, Dc, fb_hits, scale, cbits);
                 else
-                    own_run<N, V, false, true>(acc, s, recs, B, hits, D, Dc, fb_hits, scale, cbits);
+                    own_run<N, V, false, true, false>(acc, s, recs, B, hits, D, Dc, fb_hits, scale, cbits);
             } else if constexpr (!own_fixed(N, V)) {
                 if (fb)
-                    own_run<N, V, true, false>(acc, s, recs, B, hits, D, Dc, fb_hits, scale, cbits);
+                    own_run<N, V, true, false, false>(acc, s, recs, B, hits, D, Dc, fb_hits, scale, cbits);
                 else
-                    own_run<N, V, false, false>(acc, s, recs, B, hits, D, Dc, fb_hits, scale, cbits);
+                    own_run<N, V, false, false, false>(acc, s, recs, B, hits, D, Dc, fb_hits, scale, cbits);
             }
         } else
             own_dispatch<N, V + 1>(acc, s, recs, B, hits, D, Dc, fb_hits, scale, cbits);
@@ -609,8 +695,8 @@ __device__ __forceinline__ void own_dispatch(float* acc, const Slice& s, const T
 template <int N>
 __global__ __launch_bounds__(OWN_WG) void k_td_update_owner(float* dst, float* cdst, TdRecs recs, uint32_t B, const Slice* slices, uint32_t* hits,
                                                             uint64_t* wg_clock) {
-    __shared__ float acc[OWN_SLOTS];
-    __shared__ uint32_t fb_hits[64];
+    __shared__ __attribute__((aligned(16))) float acc[OWN_SLOTS];
+    __shared__ __attribute__((aligned(8))) uint32_t fb_hits[FB_WORDS];         // 64 fallback hit counters + the fallback cache (fb_add)
     const Slice s = slices[blockIdx.x];
     if (threadIdx.x == 0) wg_clock[2 * blockIdx.x] = wall_clock64();    // feeds the planner; g2048_debug_owner_plan shows them
     const bool fixed = own_fixed(N, (int)s.variant) || s.fixed;
@@ -633,8 +719,17 @@ __global__ __launch_bounds__(OWN_WG) void k_td_update_owner(float* dst, float* c
         inv_scale = ldexpf(1.0f, -S);
     }
     const uint32_t words = fixed ? 2 * s.size : s.size;        // a fixed-point slot is two LDS words
-    for (uint32_t j = threadIdx.x; j < words; j += OWN_WG) acc[j] = 0.0f;
+    {   // (16 bytes per store: 2.0 -> 1.x us per workgroup; words is a multiple of 4)
+        float4* const acc4 = reinterpret_cast<float4*>(acc);
+        for (uint32_t j = threadIdx.x; j < words / 4u; j += OWN_WG) acc4[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
     if (threadIdx.x < 64) fb_hits[threadIdx.x] = 0;
+    if (s.fb_mask) {
+        for (uint32_t j = threadIdx.x; j < FB_CACHE; j += OWN_WG) {
+            fb_keys(fb_hits)[j] = FB_EMPTY;
+            fb_vals(fb_hits)[j] = 0ull;
+        }
+    }
     __syncthreads();
     own_dispatch<N, 0>(acc, s, recs, B, hits, dst, cdst, fb_hits, scale, cbits);
     __syncthreads();
@@ -644,6 +739,7 @@ __global__ __launch_bounds__(OWN_WG) void k_td_update_owner(float* dst, float* c
         float v, cnt = 0.0f;
         if (fixed) {
             const unsigned long long word = reinterpret_cast<const unsigned long long*>(acc)[j];
+            if (word == 0ull) continue;                                        // (untouched: most slots of most chunks)
             const unsigned long long n = word & cmask;                         // (0 without count bits)
             v = (float)((double)((long long)(word - n) >> cbits) * (double)inv_scale);
             cnt = (float)n;
@@ -656,6 +752,17 @@ __global__ __launch_bounds__(OWN_WG) void k_td_update_owner(float* dst, float* c
         } else {
             if (v != 0.0f) __hip_atomic_fetch_add(&dst[s.dlo + j], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (cnt != 0.0f) __hip_atomic_fetch_add(&cdst[s.dlo + j], cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (s.fb_mask && fixed) {       // what the fallback cache holds: one add per slot and workgroup
+        for (uint32_t j = threadIdx.x; j < FB_CACHE; j += OWN_WG) {
+            const uint32_t dslot = fb_keys(fb_hits)[j];
+            if (dslot == FB_EMPTY) continue;
+            const unsigned long long word = fb_vals(fb_hits)[j];
+            const unsigned long long n = word & cmask;
+            const float v = (float)((double)((long long)(word - n) >> cbits) * (double)inv_scale);
+            if (v != 0.0f) __hip_atomic_fetch_add(&dst[dslot], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (n) __hip_atomic_fetch_add(&cdst[dslot], (float)n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     if (threadIdx.x == 0) wg_clock[2 * blockIdx.x + 1] = wall_clock64();
@@ -733,7 +840,7 @@ __device__ __forceinline__ void add_to_members(float* w, float* dacc, const Orbi
 // a clear in place would race with the threads that read E[sigma(k)]; a memset between the steps costs a launch and, in
 // ROCclr, ~20 us of idle queue); the f_6 orbit tables behind them live in D and are cleared in place.
 __global__ __launch_bounds__(WG) void k_apply_orbits(float* w, float* dacc, float* D, const float* cur, float* oth, uint32_t owned, OrbitTable t,
-                                                      StatMirror sm) {
+                                                      StatMirror sm, uint32_t quad_plain) {
     mirror_stats(sm);
     if (blockIdx.x < mirror_blocks(sm)) return;
     const uint32_t K = (blockIdx.x - mirror_blocks(sm)) * WG + threadIdx.x;
@@ -744,8 +851,9 @@ __global__ __launch_bounds__(WG) void k_apply_orbits(float* w, float* dacc, floa
     for (uint32_t j = 1; j < MAX_ORBITS; ++j)
         if (j < t.count && K >= t.o[j].base) o = j;
     const OrbitInfo& oi = t.o[o];
-    const bool cross = oi.radix == 16u && oi.digits == 5u;              // its table is in cross_order
-    const uint32_t k = cross ? cross_unorder(K - oi.base) : K - oi.base;
+    const bool cross = oi.radix == 16u && oi.digits == 5u, quad = oi.radix == 16u && oi.digits == 4u;    // tables in cross_order / quad_place order
+    uint32_t k = cross ? cross_unorder(K - oi.base) : K - oi.base;
+    if (quad && !quad_unplace(K - oi.base, k, quad_plain != 0u)) return;                  // (a hole of the four-cell order)
     float v;
     uint32_t k2 = k;        // f_6 orbit with a stabiliser {e, sigma}: the thread of the smaller of k, sigma(k) serves both
     if (K >= owned) {
@@ -764,7 +872,7 @@ __global__ __launch_bounds__(WG) void k_apply_orbits(float* w, float* dacc, floa
         v = cur[K];
         for (uint32_t s = 1; s < oi.nstab; ++s) {
             const uint32_t j = permute_digits(k, oi.sperm[s], oi.digits, oi.radix);
-            v += cur[oi.base + (cross ? cross_order(j) : j)];
+            v += cur[oi.base + (cross ? cross_order(j) : quad ? (quad_plain ? QUAD_HOT + j : quad_place(j)) : j)];
         }
         if (v == 0.0f) return;
     }
@@ -775,7 +883,7 @@ __global__ __launch_bounds__(WG) void k_apply_orbits(float* w, float* dacc, floa
 // Per-slot mean rule (g2048_set_update_rule): S = sum of the dw that target a slot, C = how many did; the slot moves
 // by S / C.  S and C come from two runs of the same accumulation (the second with dw = 1).
 __global__ __launch_bounds__(WG) void k_apply_orbits_mean(float* w, float* dacc, float* S, float* C, const float* scur, const float* ccur, float* soth,
-                                                          float* coth, uint32_t owned, OrbitTable t, StatMirror sm) {
+                                                          float* coth, uint32_t owned, OrbitTable t, StatMirror sm, uint32_t quad_plain) {
     mirror_stats(sm);
     if (blockIdx.x < mirror_blocks(sm)) return;
     const uint32_t K = (blockIdx.x - mirror_blocks(sm)) * WG + threadIdx.x;
@@ -789,8 +897,9 @@ __global__ __launch_bounds__(WG) void k_apply_orbits_mean(float* w, float* dacc,
     for (uint32_t j = 1; j < MAX_ORBITS; ++j)
         if (j < t.count && K >= t.o[j].base) o = j;
     const OrbitInfo& oi = t.o[o];
-    const bool cross = oi.radix == 16u && oi.digits == 5u;
-    const uint32_t k = cross ? cross_unorder(K - oi.base) : K - oi.base;
+    const bool cross = oi.radix == 16u && oi.digits == 5u, quad = oi.radix == 16u && oi.digits == 4u;
+    uint32_t k = cross ? cross_unorder(K - oi.base) : K - oi.base;
+    if (quad && !quad_unplace(K - oi.base, k, quad_plain != 0u)) return;
     float cnt, sum;
     uint32_t k2 = k;
     if (K >= owned) {
@@ -814,7 +923,7 @@ __global__ __launch_bounds__(WG) void k_apply_orbits_mean(float* w, float* dacc,
         sum = scur[K];
         for (uint32_t s = 1; s < oi.nstab; ++s) {
             const uint32_t pj = permute_digits(k, oi.sperm[s], oi.digits, oi.radix);
-            const uint32_t j = oi.base + (cross ? cross_order(pj) : pj);
+            const uint32_t j = oi.base + (cross ? cross_order(pj) : quad ? (quad_plain ? QUAD_HOT + pj : quad_place(pj)) : pj);
             cnt += ccur[j];
             sum += scur[j];
         }
@@ -1517,6 +1626,14 @@ struct g2048_ctx {
     uint32_t replan_interval = 1;   // steps until the next unconditional replan: 1, 2, 4, ... replan_every after a (re)start
     double makespan_ref = 0;        // owner kernel makespan (100 MHz ticks) of the first launch under the current plan
     bool plan_measured = false;     // the load is a measurement (not the creation-time prior)
+    // QuadOrder.  The four-cell orbits' tables start "hot first" (features.hpp, quad_place: the indices with every cell <= 10 in
+    // chunk 0, which then holds every add of an agent that makes no 2 048s: one scan per orbit instead of 2 - 3).  Once boards
+    // with bigger tiles send more than a few per cent of an orbit's adds elsewhere, the four chunks behind chunk 0 would all
+    // be worth holding — five scans where the plain index order needs four — so the context then switches to the plain order
+    // (every index in [QUAD_HOT, QUAD_HOT + 65 536), chunk 0 unused) until g2048_reset.  D is empty between two steps, which is
+    // when replan() switches.  G2048_QUAD_ORDER = hot | plain pins it.
+    bool quad_plain = false;
+    bool discard_stats = false;     // the hit counters not read yet were counted before a g2048_reset changed the order back: skip them once
     hipEvent_t ev_table = nullptr;  // last table-touching launch on `stream` (contexts that share a table wait on it)
     g2048_ctx* parent = nullptr;    // owner of the shared table (g2048_create_shared); null: this context owns `w`
     uint32_t shared_users = 0;      // (owner only) contexts created on this table with g2048_create_shared and still alive
@@ -1529,6 +1646,9 @@ struct g2048_ctx {
         double add_cost = 3.0, thr = 0.01, fixed_ratio = 0.25;
         int plan_feedback = 1, plan_xcd = 1, debug_plan = 0;
         double plan_mixed = 6.0;        // XCD-resident plan: chunks that deserve fewer workgroups than this are scanned flat (0: none)
+        int quad_order = 0;             // 0: hot first, switching to the plain order by the measured shares; 1: always hot first; 2: always plain
+        double quad_switch = 0.96;      // switch when chunk 0 holds less than this share of the four-cell orbits' adds
+        double plan_fixed_us = 3.0;     // the part of a workgroup's time that does not shrink with its share of the records (planner's cost model)
         unsigned play_wgs = 0;
         uint32_t play_dynamic = 2;      // full rounds of k_td_play's lane blocks left to the counter (besides the last, partial one)
         uint32_t sort_every = 8;        // default of g2048_set_lane_sort for new contexts (G2048_SORT_EVERY); 0 = never
@@ -1630,6 +1750,9 @@ void read_knobs(g2048_ctx* c) {
     if (const char* e = getenv("G2048_PLAN_FEEDBACK")) k.plan_feedback = atoi(e);
     if (const char* e = getenv("G2048_PLAN_XCD")) k.plan_xcd = atoi(e);
     if (const char* e = getenv("G2048_PLAN_MIXED")) k.plan_mixed = atof(e);
+    if (const char* e = getenv("G2048_PLAN_FIXED_US")) k.plan_fixed_us = atof(e);
+    if (const char* e = getenv("G2048_QUAD_ORDER")) k.quad_order = !strcmp(e, "hot") ? 1 : !strcmp(e, "plain") ? 2 : 0;
+    if (const char* e = getenv("G2048_QUAD_SWITCH")) k.quad_switch = atof(e);
     if (getenv("G2048_DEBUG_PLAN")) k.debug_plan = 1;
     if (const char* e = getenv("G2048_PLAY_WGS")) k.play_wgs = (unsigned)atoi(e);
     if (const char* e = getenv("G2048_PLAY_DYNAMIC")) k.play_dynamic = (uint32_t)atoi(e);
@@ -1846,7 +1969,7 @@ int find_orbits(g2048_ctx* c) {
             OrbitInfo& oi = T.o[T.count++];
             oi = OrbitInfo{};
             oi.base = T.total;
-            oi.size = feature_size(N, i);
+            oi.size = (N >= 4 && nd == 4u) ? QUAD_DSIZE : feature_size(N, i);       // (four-cell orbits: quad_place order, features.hpp)
             oi.digits = nd;
             oi.radix = radix;
             oi.nmem = 1;
@@ -2012,9 +2135,10 @@ int build_slices(g2048_ctx* c) {
         for (size_t k = 0; k < nc; ++k) {       // fresh games only touch small tiles: the low chunk of every table
             double share = 1.0;
             if (c->n >= 4) {
-                const uint32_t rel = (chunks[k].dlo % (chunks[k].scan == 1.0 ? 65536u : 1048576u)) / chunks[k].size;
+                const uint32_t rel = (chunks[k].dlo - chunks[k].orb_dlo) / chunks[k].size;
                 const uint32_t per16 = 65536u / chunks[k].size;       // chunks per value of the cross's leading nibble
-                share = chunks[k].scan == 1.0 ? (rel == 0 ? 0.7 : rel == 1 ? 0.28 : 0.01) : (rel % per16 == 0 && rel < 8 * per16 ? 0.12 : 0.001);
+                const double quad_share = c->quad_plain ? (rel == 0 ? 0.0 : rel == 1 ? 0.7 : rel == 2 ? 0.28 : 0.01) : (rel == 0 ? 0.98 : 0.005);
+                share = chunks[k].scan == 1.0 ? quad_share : (rel % per16 == 0 && rel < 8 * per16 ? 0.12 : 0.001);
             }
             c->load[k] = 8.0 * c->B * share * (c->n == 2 ? 3 : c->n == 3 ? 3.25 : 1);      // (n = 2, 3: 24 / 26 adds per record and chunk)
         }
@@ -2029,15 +2153,21 @@ int build_slices(g2048_ctx* c) {
             const size_t cnt = chunks[k0].orb_chunks;
             double orbit_total = 0;
             size_t best = k0;
+            if (c->quad_plain && chunks[k0].scan == 1.0 && cnt > 1) best = k0 + 1;
             for (size_t j = k0; j < k0 + cnt; ++j) {
                 orbit_total += c->load[j];
                 if (c->load[j] > c->load[best]) best = j;
             }
-            for (size_t j = k0; j < k0 + cnt; ++j)
+            for (size_t j = k0; j < k0 + cnt; ++j) {
+                if (c->quad_plain && chunks[j].scan == 1.0 && j == k0) {       // (plain order: chunk 0 of a four-cell orbit receives nothing)
+                    in_lds[j] = 0;
+                    continue;
+                }
                 if (j != best && c->load[j] < thr * orbit_total) {
                     in_lds[j] = 0;
                     duty[best] |= 1ull << (j - k0);
                 }
+            }
         }
     std::vector<double> cost(nc, 0.0);
     double total = 0;
@@ -2075,7 +2205,7 @@ int build_slices(g2048_ctx* c) {
     auto slice_of = [&](size_t k, uint32_t p, uint32_t np) {
         return Slice{chunks[k].variant, chunks[k].tlo, chunks[k].size, chunks[k].dlo, p, np, (uint32_t)k,
                      chunks[k].orb_tlo, chunks[k].orb_dlo, chunks[k].chunk0, duty[k], chunks[k].size >= OWN_SLOTS ? 15u : 14u,
-                     chunk_fixed(c, (int)chunks[k].variant) ? 1u : 0u, 0u};
+                     chunk_fixed(c, (int)chunks[k].variant) ? 1u : 0u, 0u, c->quad_plain ? 1u : 0u};
     };
     // 0: flat plan; 1 (default where it applies): XCD-resident scan.  (Cutting the chunks into pieces packed onto the 32
     // workgroups of an XCD, a workgroup running its pieces one after the other, was tried: 0.296 -> 0.311 ms per step.)
@@ -2180,6 +2310,40 @@ int build_slices(g2048_ctx* c) {
     return G2048_OK;
 }
 
+// QuadOrder (see g2048_ctx): is chunk 0's share of the four-cell orbits' adds below the switch point?
+bool quad_order_due(const g2048_ctx* c) {
+    if (c->n < 4 || c->quad_plain || c->knob.quad_order != 0) return false;
+    const std::vector<ChunkInfo> chunks = table_chunks(c);
+    double hot = 0, all = 0;
+    for (size_t k = 0; k < chunks.size() && k < c->load.size(); ++k) {
+        if (chunks[k].scan != 1.0) continue;
+        all += c->load[k];
+        if (k == chunks[k].chunk0) hot += c->load[k];
+    }
+    return all > 0 && hot < c->knob.quad_switch * all;
+}
+// Switch the order in which the four-cell orbits' tables are used (between two steps: D is empty).  The loads measured under
+// the old order mean nothing under the new one: back to a prior with the same totals, measured again from the next step on.
+int set_quad_plain(g2048_ctx* c, bool plain) {
+    const std::vector<ChunkInfo> chunks = table_chunks(c);
+    for (size_t k0 = 0; k0 < chunks.size() && k0 < c->load.size(); k0 += chunks[k0].orb_chunks) {
+        if (chunks[k0].scan != 1.0) continue;
+        const size_t cnt = chunks[k0].orb_chunks;
+        double total = 0;
+        for (size_t j = k0; j < k0 + cnt; ++j) total += c->load[j];
+        for (size_t j = k0; j < k0 + cnt; ++j) {
+            const size_t rel = j - k0;
+            c->load[j] = total * (plain ? (rel == 0 ? 0.0 : rel == 1 ? 0.7 : rel == 2 ? 0.28 : 0.01) : (rel == 0 ? 0.98 : 0.005));
+        }
+    }
+    c->quad_plain = plain;
+    c->work.clear();
+    c->plan_measured = false;
+    c->replan_interval = 1;
+    if (c->knob.debug_plan) fprintf(stderr, "[g2048 plan] four-cell orbit tables: %s order from here on\n", plain ? "plain" : "hot-first");
+    return build_slices(c);
+}
+
 // Planner feedback, first half (BEFORE the step's k_td_play is launched): the hit counters and the workgroup clocks of
 // the update launches so far were stored into pinned host memory by the previous step's apply kernel (mirror_stats); an
 // event marks that kernel's end.
@@ -2233,6 +2397,12 @@ int replan(g2048_ctx* c) {
         HIP_TRY(c, hipEventSynchronize(c->ev_plan));
     }
     const uint32_t* h = reinterpret_cast<const uint32_t*>(c->h_stat);
+    if (c->discard_stats) {
+        c->discard_stats = false;
+        for (size_t k = 0; k < c->n_chunks; ++k) c->hits_seen[k] = h[k];
+        c->steps_since_read = 0;
+        return G2048_OK;
+    }
     uint64_t fresh_total = 0;
     for (size_t k = 0; k < c->n_chunks; ++k) fresh_total += h[k] - c->hits_seen[k];          // cumulative counters, modulo 2^32
     // steps without records (the first move of fresh games makes none) say nothing about the load: keep what we have
@@ -2249,11 +2419,12 @@ int replan(g2048_ctx* c) {
         return G2048_OK;
     }
     c->plan_measured = true;
+    if (quad_order_due(c)) return set_quad_plain(c, true);
     // the last launch's workgroup clocks: work of a chunk = (mean duration - fixed part) x its workgroups
     double makespan = 0;
     if (c->plan.size() == c->n_slices && c->n_slices) {
         const uint64_t* clk = reinterpret_cast<const uint64_t*>(c->h_stat + HITS_CAP * 4);
-        const double fixed_ticks = 300.0;                   // LDS clear + flush, ~3 us of the 100 MHz clock
+        const double fixed_ticks = 100.0 * c->knob.plan_fixed_us;          // (100 MHz clock)
         std::vector<double> sum(c->n_chunks, 0.0);
         std::vector<uint32_t> cnt(c->n_chunks, 0);
         uint64_t first = ~0ull, last = 0;
@@ -2443,9 +2614,9 @@ int launch_td_step(g2048_ctx* c, float alpha, hipEvent_t ev = nullptr, hipEvent_
         OrbitTable ot = c->orbits;
         if (hex_binned) ot.total = c->owned_total;      // the f_6 orbit tables are applied chunk by chunk (k_hex_apply)
         if (c->update_rule == 1)
-            k_apply_orbits_mean<<<grid_for(ot.total) + mirror_blocks(sm), WG, 0, c->stream>>>(c->w, dacc, c->D, c->Dcnt, Dcur, Ccur, Doth, Coth, c->owned_total, ot, sm);
+            k_apply_orbits_mean<<<grid_for(ot.total) + mirror_blocks(sm), WG, 0, c->stream>>>(c->w, dacc, c->D, c->Dcnt, Dcur, Ccur, Doth, Coth, c->owned_total, ot, sm, c->quad_plain ? 1u : 0u);
         else
-            k_apply_orbits<<<grid_for(ot.total) + mirror_blocks(sm), WG, 0, c->stream>>>(c->w, dacc, c->D, Dcur, Doth, c->owned_total, ot, sm);
+            k_apply_orbits<<<grid_for(ot.total) + mirror_blocks(sm), WG, 0, c->stream>>>(c->w, dacc, c->D, Dcur, Doth, c->owned_total, ot, sm, c->quad_plain ? 1u : 0u);
         if (hex_binned) {
             const uint32_t hb = c->orbits.o[6].base;
             k_hex_apply<<<grid_for(HEX_SLOTS), WG, 0, c->stream>>>(c->w, dacc, c->D + hb, c->update_rule == 1 ? c->Dcnt + hb : nullptr, c->hex, c->orbits.o[6], c->orbits.o[7]);
@@ -2592,6 +2763,7 @@ static int create_impl(int device, uint32_t batch, int n_tuple, uint64_t seed, u
         hipEventCreateWithFlags(&c->ev_table, hipEventDisableTiming) != hipSuccess)
         return bail(G2048_ERR_HIP);
     read_knobs(c);
+    c->quad_plain = c->knob.quad_order == 2;
     // (n = 3: its LDS set holds the entries whose three cells are all below 8, so "big" for the lane order starts at 256 there)
     if (n_tuple == 3 && !getenv("G2048_SORT_TILE")) c->knob.sort_tile = 7;
     const size_t B = batch;
@@ -2718,6 +2890,10 @@ int g2048_reset(g2048_ctx* c) {
     NEED_IDENTITY(c);
     c->replan_interval = 1;         // the tile distribution restarts: follow it closely again
     c->hex_young = HEX_YOUNG_STEPS;
+    if (c->n >= 4 && c->quad_plain && c->knob.quad_order == 0 && c->slices) {
+        c->discard_stats = true;
+        if (int rc = set_quad_plain(c, false)) return rc;       // young boards again: hot-first (QuadOrder)
+    }
     k_new_games<<<grid_for(c->B), WG, 0, c->stream>>>(c->boards, c->scores, c->rng, c->label, c->flags, c->B);
     if (c->log.lanes) k_log_init<<<grid_for(c->log.lanes), WG, 0, c->stream>>>(c->log, c->boards, c->flags);
     return launched(c, "k_new_games");

@@ -141,6 +141,23 @@ int hc_memory_slots(int n, const uint8_t* boards, int64_t count, int32_t* out) {
     }
     return 0;
 }
+// the four-cell orbits' table order: place[k], hot[k] for k < 65536; unplace[K] (-1: hole) for K < QUAD_DSIZE; and the two-at-a-time
+// forms on the word k | k2 << 16 for `pairs` pairs (k, k2)
+int hc_quad_place(uint32_t* place, uint8_t* hot, int32_t* unplace, int64_t pairs, const uint32_t* words, uint32_t* big, uint32_t* b11) {
+    for (uint32_t k = 0; k < 65536u; ++k) {
+        place[k] = quad_place(k);
+        hot[k] = quad_is_hot(k) ? 1 : 0;
+    }
+    for (uint32_t K = 0; K < QUAD_DSIZE; ++K) {
+        uint32_t k = 0;
+        unplace[K] = quad_unplace(K, k) ? (int32_t)k : -1;
+    }
+    for (int64_t i = 0; i < pairs; ++i) {
+        big[i] = quad_big_nibbles(words[i]);
+        b11[i] = quad_base11_halves(words[i]);
+    }
+    return (int)QUAD_DSIZE;
+}
 void hc_cross_order(int64_t count, uint32_t* fwd, uint32_t* back) {       // cross_order(k) and cross_unorder(k) for k = 0 .. count-1
     for (int64_t k = 0; k < count; ++k) {
         fwd[k] = cross_order((uint32_t)k);

@@ -363,6 +363,48 @@ def test_td_hot_set_path_vs_oracle(n, B, monkeypatch):
     eng.close()
 
 
+@pytest.mark.parametrize('rule', ['sum', 'mean'])
+@pytest.mark.parametrize('order', ['auto', 'hot', 'plain'])
+@pytest.mark.parametrize('n', [4, 5])
+def test_td_four_cell_orbit_table_orders(n, order, rule, monkeypatch):
+    """The four-cell orbits' accumulation tables (features.hpp, quad_place; g2048.hip, QuadOrder): hot-first (every index whose
+    cells are all <= 10 in chunk 0) for young boards, the plain index order once bigger tiles send more than a few per cent of the
+    adds elsewhere, back to hot-first at g2048_reset.  Every step is the oracle's step under either order, pinned
+    (G2048_QUAD_ORDER) or chosen by the context, through the switch and back; which order is in force shows in the plan:
+    chunks 0, 5, 10, 15, 20 (the orbits' first chunks) have workgroups only under the hot-first order."""
+    if order != 'auto':
+        monkeypatch.setenv('G2048_QUAD_ORDER', order)
+    monkeypatch.setenv('G2048_REPLAN_EVERY', '1')            # the planner looks at the measured shares after every step
+    B = 8192
+    eng = Engine(B, n=n, seed=4100 + n)
+    eng.set_auto_reset(False)
+    eng.set_update_rule(1 if rule == 'mean' else 0)
+    eng.step_random(30)
+
+    def first_chunks_in_plan():
+        plan = eng.debug_owner_plan().astype(np.int64)
+        return sorted(set(plan[:, 1].tolist()) & {0, 5, 10, 15, 20})
+
+    for t in range(3):
+        helpers.check_td_step(eng, n, formulas.exact_alpha(n), formulas.weights(n, scale=2.0 ** -(4 + t)), rule=rule)
+    assert first_chunks_in_plan() == ([] if order == 'plain' else [0, 5, 10, 15, 20])
+    r = np.random.RandomState(n)
+    boards = (r.randint(0, 14, (B, 4, 4)) * (r.rand(B, 4, 4) < 0.8)).astype(np.uint8)       # most tuples hold a cell >= 11
+    boards[:512] = r.randint(0, 9, (512, 4, 4))
+    boards[:, 0, 0] = 0
+    boards[:, 1, 1] = np.maximum(boards[:, 1, 1], 1)
+    eng.set_boards(boards)
+    for t in range(4):
+        helpers.check_td_step(eng, n, formulas.exact_alpha(n), formulas.weights(n, scale=2.0 ** -(5 + t % 3)), rule=rule)
+    assert first_chunks_in_plan() == ([0, 5, 10, 15, 20] if order == 'hot' else [])          # (auto: switched)
+    eng.reset()
+    eng.step_random(20)
+    for t in range(3):
+        helpers.check_td_step(eng, n, formulas.exact_alpha(n), formulas.weights(n, scale=2.0 ** -(4 + t)), rule=rule)
+    assert first_chunks_in_plan() == ([] if order == 'plain' else [0, 5, 10, 15, 20])          # (auto: hot-first again)
+    eng.close()
+
+
 @pytest.mark.parametrize('lag', [2, 0])
 @pytest.mark.parametrize('n', [3, 4, 5, 6])
 def test_lane_sort_is_invisible(n, lag, monkeypatch):

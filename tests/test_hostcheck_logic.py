@@ -298,3 +298,34 @@ def test_cross_order_is_a_bijection_with_the_cells_high_bits_on_top(hc):
         for j in range(5):
             want |= ((cells[j] >> b) & 1).astype(np.uint32) << np.uint32(5 * b + j)
     assert np.array_equal(fwd, want)
+
+
+def test_quad_place_order_of_the_four_cell_orbit_tables(hc):
+    """The four-cell orbits' accumulation tables (features.hpp, quad_place): the 11^4 indices with every cell <= 10 first, as
+    base-11 numbers inside the first 16 384 slots, then the 16-bit index space in index order of which only indices with a cell
+    >= 11 are used; quad_unplace is the inverse and reports the holes; the two-indices-per-word forms the owner kernel uses
+    agree with the scalar ones on every half."""
+    dsize = 16384 + 65536
+    place, hot, unplace = np.zeros(65536, np.uint32), np.zeros(65536, np.uint8), np.zeros(dsize, np.int32)
+    rng = np.random.default_rng(5)
+    words = np.concatenate([rng.integers(0, 1 << 32, 200000, dtype=np.uint64).astype(np.uint32),
+                            (np.arange(65536, dtype=np.uint32) << 16) | np.arange(65536, dtype=np.uint32)[::-1]])
+    big, b11 = np.zeros(len(words), np.uint32), np.zeros(len(words), np.uint32)
+    assert hc.hc_quad_place(ptr(place), ptr(hot), ptr(unplace), ctypes.c_int64(len(words)), ptr(words), ptr(big), ptr(b11)) == dsize
+    k = np.arange(65536, dtype=np.int64)
+    cells = np.stack([(k >> s) & 15 for s in (12, 8, 4, 0)], axis=1)
+    want_hot = (cells <= 10).all(axis=1)
+    assert np.array_equal(hot.astype(bool), want_hot)
+    base11 = ((cells[:, 0] * 11 + cells[:, 1]) * 11 + cells[:, 2]) * 11 + cells[:, 3]
+    assert np.array_equal(place.astype(np.int64), np.where(want_hot, base11, 16384 + k))
+    assert len(np.unique(place)) == 65536 and place[want_hot].max() == 11 ** 4 - 1
+    used = np.zeros(dsize, bool)
+    used[place] = True
+    assert np.array_equal(unplace >= 0, used)                               # every other slot is a hole
+    assert np.array_equal(unplace[place], k)
+    for half, w in ((0, words & 0xFFFF), (1, words >> 16)):
+        w = w.astype(np.int64)
+        bh = (big >> (16 * half)) & 0xFFFF
+        assert np.array_equal(bh == 0, want_hot[w])
+        ok = want_hot[w]
+        assert np.array_equal(((b11 >> (16 * half)) & 0xFFFF)[ok].astype(np.int64), base11[w][ok])
