@@ -392,24 +392,11 @@ __device__ __forceinline__ unsigned long long packed_add(float dw, double scale,
     return fixed;
 }
 
-// Fallback adds — to chunks of the orbit that no workgroup holds — first meet in a small direct-mapped {D slot, packed sum} cache
-// in the 32 KB of LDS the accumulators leave free (behind the 64 fallback hit counters of `fb_hits`): memory-side atomics
-// serialise per address, and what young boards send to a light chunk lands on a handful of its slots (a fallback share of 3 %
-// cost 70 us of global atomics per launch without this).  Only a slot that finds its cache line taken goes to D directly.
-// The words are the workgroup's own packed fixed-point adds (packed_add); the flush in k_td_update_owner splits them again.
-constexpr uint32_t FB_CACHE = 2048u, FB_EMPTY = 0xFFFFFFFFu, FB_WORDS = 64u + FB_CACHE + 2u * FB_CACHE;
-__device__ __forceinline__ uint32_t* fb_keys(uint32_t* fb_hits) { return fb_hits + 64; }
-__device__ __forceinline__ unsigned long long* fb_vals(uint32_t* fb_hits) { return reinterpret_cast<unsigned long long*>(fb_hits + 64 + FB_CACHE); }
-template <bool FIXED>
-__device__ __forceinline__ void fb_add(uint32_t* fb_hits, float* D, float* Dc, uint32_t dslot, float dw, double scale, uint32_t cbits) {
-    if (FIXED) {
-        const uint32_t h = (dslot * 2654435761u) >> 21;                 // 11 bits
-        const uint32_t prev = atomicCAS(&fb_keys(fb_hits)[h], FB_EMPTY, dslot);
-        if (prev == FB_EMPTY || prev == dslot) {
-            atomicAdd(&fb_vals(fb_hits)[h], packed_add(dw, scale, cbits));
-            return;
-        }
-    }
+// A fallback add — to a chunk of the orbit that no workgroup holds — goes straight to D.  (A small {D slot, packed sum} cache in
+// the 32 KB of LDS the accumulators leave free was tried for them: a compare-and-swap round trip inside divergent code per add;
+// it cut the cost of a 3 % fallback share from 70 to 27 us per launch and slowed a trained agent's step, whose fallback adds are
+// spread thin, by 2 - 4 %: profiles/r04_experiments.txt item 11.)
+__device__ __forceinline__ void fb_add(float* D, float* Dc, uint32_t dslot, float dw) {
     __hip_atomic_fetch_add(&D[dslot], dw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (Dc) __hip_atomic_fetch_add(&Dc[dslot], 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -442,7 +429,7 @@ __device__ __forceinline__ void own_accum(const Packed& p, float dw, bool valid,
             if (FB && valid && !hit) {
                 const uint32_t rel = orel, ch = rel >> sl.cshift;
                 if ((sl.fb_mask >> ch) & 1u) {
-                    fb_add<FIXED>(fb_hits, D, Dc, sl.orb_dlo + rel, dw, (double)scale, cbits);
+                    fb_add(D, Dc, sl.orb_dlo + rel, dw);
                     atomicAdd(&fb_hits[ch], 1u);            // LDS counter, flushed once per workgroup
                 }
             }
@@ -473,7 +460,9 @@ __device__ __forceinline__ void own_accum_small(const Packed& p, float dw, bool 
 }
 
 // the same accumulation from precomputed orbit indices (k_td_play's OrbitIdx records); idx are relative to the orbit table
-template <int NI, bool FB, bool FIXED>
+// (BIAS: what a fallback add puts on top of the index to get its place — QUAD_HOT for the four-cell orbits in plain order, whose
+// records hold plain indices and whose `lo_rel` the caller has lowered by as much)
+template <int NI, bool FB, bool FIXED, uint32_t BIAS = 0u>
 __device__ __forceinline__ void own_accum_idx(const uint32_t (&idx)[NI], float dw, bool valid, float* acc, const Slice& sl, uint32_t lo_rel,
                                               uint32_t& nhit_lane, float* D, float* Dc, uint32_t* fb_hits, double scale, uint32_t cbits) {
     // A scan is bound by instruction issue (~0.46 ns per record and workgroup whether the record is 12 or 20 bytes,
@@ -504,9 +493,9 @@ __device__ __forceinline__ void own_accum_idx(const uint32_t (&idx)[NI], float d
 #pragma unroll
         for (int j = 0; j < NI; ++j)
             if (!hit[j]) {
-                const uint32_t rel = idx[j], ch = rel >> sl.cshift;
+                const uint32_t rel = idx[j] + BIAS, ch = rel >> sl.cshift;
                 if ((sl.fb_mask >> ch) & 1u) {
-                    fb_add<FIXED>(fb_hits, D, Dc, sl.orb_dlo + rel, dw, (double)scale, cbits);
+                    fb_add(D, Dc, sl.orb_dlo + rel, dw);
                     atomicAdd(&fb_hits[ch], 1u);            // LDS counter, flushed once per workgroup
                 }
             }
@@ -531,7 +520,7 @@ __device__ __forceinline__ void own_accum_quad(uint32_t x, uint32_t y, float dw,
             const int j = 2 * p + h;
             const uint32_t big_h = h ? big >> 16 : big & 0xFFFFu, idx = h ? w[p] >> 16 : w[p] & 0xFFFFu;
             local[j] = HOT ? (h ? b11 >> 16 : b11 & 0xFFFFu) : idx - lo16;
-            hit[j] = valid && (HOT ? big_h == 0u : ((big_h != 0u || sl.quad_plain) && local[j] < QUAD_HOT));
+            hit[j] = valid && (HOT ? big_h == 0u : (big_h != 0u && local[j] < QUAD_HOT));
             any |= hit[j];
             nhit_lane += hit[j] ? 1u : 0u;
         }
@@ -547,16 +536,17 @@ __device__ __forceinline__ void own_accum_quad(uint32_t x, uint32_t y, float dw,
         for (int j = 0; j < NI; ++j)
             if (!hit[j]) {
                 const uint32_t idx = (j & 1) ? w[j >> 1] >> 16 : w[j >> 1] & 0xFFFFu;
-                const uint32_t rel = (HOT || sl.quad_plain) ? QUAD_HOT + idx : quad_place(idx), ch = rel >> sl.cshift;       // (a miss of chunk 0 has a cell >= 11)
+                const uint32_t rel = HOT ? QUAD_HOT + idx : quad_place(idx), ch = rel >> sl.cshift;       // (a miss of chunk 0 has a cell >= 11)
                 if ((sl.fb_mask >> ch) & 1u) {
-                    fb_add<true>(fb_hits, D, Dc, sl.orb_dlo + rel, dw, scale, cbits);
+                    fb_add(D, Dc, sl.orb_dlo + rel, dw);
                     atomicAdd(&fb_hits[ch], 1u);
                 }
             }
     }
 }
 
-template <int N, int V, bool FB, bool FIXED, bool HOT>
+// KIND (four-cell orbits, V < 5): 1 = chunk 0 of the hot-first order, 2 = one of the chunks behind it, 3 = plain order (QuadOrder); else 0
+template <int N, int V, bool FB, bool FIXED, int KIND>
 __device__ __forceinline__ void own_run(float* acc, const Slice& s, const TdRecs& recs, uint32_t B, uint32_t* hits, float* D, float* Dc,
                                         uint32_t* fb_hits, float scale, uint32_t cbits) {
     constexpr int F0 = OwnVariants<N>::f0(V), FC = OwnVariants<N>::fc(V);
@@ -600,10 +590,15 @@ __device__ __forceinline__ void own_run(float* acc, const Slice& s, const TdRecs
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                if constexpr (V < 5) {
+                if constexpr (V < 5 && KIND == 3) {         // plain order: the indices as they are, QUAD_HOT slots into the table
+                    uint32_t plain[NI];
+                    plain[0] = NI > 1 ? idx[u][0] & 0xFFFFu : idx[u][0];
+                    if constexpr (NI > 1) { plain[1] = idx[u][0] >> 16; plain[2] = idx[u][1] & 0xFFFFu; plain[3] = idx[u][1] >> 16; }
+                    own_accum_idx<NI, FB, FIXED, QUAD_HOT>(plain, dw[u], dw[u] != 0.0f, acc, s, lo_rel - QUAD_HOT, nhit_wave, D, Dc, fb_hits, (double)scale, cbits);
+                } else if constexpr (V < 5) {
                     static_assert(V >= 5 || FIXED, "the four-cell orbits sum in fixed point (chunks of QUAD_HOT slots)");
-                    own_accum_quad<NI, FB, HOT>(idx[u][0], idx[u][NI > 1 ? 1 : 0], dw[u], dw[u] != 0.0f, acc, s, lo_rel - QUAD_HOT, nhit_wave, D, Dc,
-                                                fb_hits, (double)scale, cbits);
+                    own_accum_quad<NI, FB, KIND == 1>(idx[u][0], idx[u][NI > 1 ? 1 : 0], dw[u], dw[u] != 0.0f, acc, s, lo_rel - QUAD_HOT, nhit_wave, D, Dc,
+                                                      fb_hits, (double)scale, cbits);
                 } else {
                     own_accum_idx<NI, FB, FIXED>(idx[u], dw[u], dw[u] != 0.0f, acc, s, lo_rel, nhit_wave, D, Dc, fb_hits, (double)scale, cbits);
                 }
@@ -663,27 +658,32 @@ __device__ __forceinline__ void own_dispatch(float* acc, const Slice& s, const T
             const bool fb = N >= 4 && s.fb_mask;
             if constexpr (N >= 4 && V < 5) {       // a four-cell orbit: chunk 0 (all cells <= 10) or one of the four behind it
                 static_assert(own_fixed(N, V) && FIXED_SLOTS == QUAD_HOT, "four-cell orbits: fixed point, chunks of QUAD_HOT slots");
-                if (s.tlo == s.orb_tlo && !s.quad_plain) {
+                if (s.quad_plain) {
                     if (fb)
-                        own_run<N, V, true, true, true>(acc, s, recs, B, hits, D, Dc, fb_hits, scale, cbits);
+                        own_run<N, V, true, true, 3>(acc, s, recs, B, hits, D, Dc, fb_hits, scale, cbits);
                     else
-                        own_run<N, V, false, true, true>(acc, s, recs, B, hits, D, Dc, fb_hits, scale, cbits);
+                        own_run<N, V, false, true, 3>(acc, s, recs, B, hits, D, Dc, fb_hits, scale, cbits);
+                } else if (s.tlo == s.orb_tlo) {
+                    if (fb)
+                        own_run<N, V, true, true, 1>(acc, s, recs, B, hits, D, Dc, fb_hits, scale, cbits);
+                    else
+                        own_run<N, V, false, true, 1>(acc, s, recs, B, hits, D, Dc, fb_hits, scale, cbits);
                 } else {
                     if (fb)
-                        own_run<N, V, true, true, false>(acc, s, recs, B, hits, D, Dc, fb_hits, scale, cbits);
+                        own_run<N, V, true, true, 2>(acc, s, recs, B, hits, D, Dc, fb_hits, scale, cbits);
                     else
-                        own_run<N, V, false, true, false>(acc, s, recs, B, hits, D, Dc, fb_hits, scale, cbits);
+                        own_run<N, V, false, true, 2>(acc, s, recs, B, hits, D, Dc, fb_hits, scale, cbits);
                 }
             } else if (own_fixed(N, V) || s.fixed) {
                 if (fb)
-                    own_run<N, V, true, true, false>(acc, s, recs, B, hits, D, Dc, fb_hits, scale, cbits);
+                    own_run<N, V, true, true, 0>(acc, s, recs, B, hits, D, Dc, fb_hits, scale, cbits);
                 else
-                    own_run<N, V, false, true, false>(acc, s, recs, B, hits, D, Dc, fb_hits, scale, cbits);
+                    own_run<N, V, false, true, 0>(acc, s, recs, B, hits, D, Dc, fb_hits, scale, cbits);
             } else if constexpr (!own_fixed(N, V)) {
                 if (fb)
-                    own_run<N, V, true, false, false>(acc, s, recs, B, hits, D, Dc, fb_hits, scale, cbits);
+                    own_run<N, V, true, false, 0>(acc, s, recs, B, hits, D, Dc, fb_hits, scale, cbits);
                 else
-                    own_run<N, V, false, false, false>(acc, s, recs, B, hits, D, Dc, fb_hits, scale, cbits);
+                    own_run<N, V, false, false, 0>(acc, s, recs, B, hits, D, Dc, fb_hits, scale, cbits);
             }
         } else
             own_dispatch<N, V + 1>(acc, s, recs, B, hits, D, Dc, fb_hits, scale, cbits);
@@ -696,7 +696,7 @@ template <int N>
 __global__ __launch_bounds__(OWN_WG) void k_td_update_owner(float* dst, float* cdst, TdRecs recs, uint32_t B, const Slice* slices, uint32_t* hits,
                                                             uint64_t* wg_clock) {
     __shared__ __attribute__((aligned(16))) float acc[OWN_SLOTS];
-    __shared__ __attribute__((aligned(8))) uint32_t fb_hits[FB_WORDS];         // 64 fallback hit counters + the fallback cache (fb_add)
+    __shared__ uint32_t fb_hits[64];
     const Slice s = slices[blockIdx.x];
     if (threadIdx.x == 0) wg_clock[2 * blockIdx.x] = wall_clock64();    // feeds the planner; g2048_debug_owner_plan shows them
     const bool fixed = own_fixed(N, (int)s.variant) || s.fixed;
@@ -724,12 +724,6 @@ __global__ __launch_bounds__(OWN_WG) void k_td_update_owner(float* dst, float* c
         for (uint32_t j = threadIdx.x; j < words / 4u; j += OWN_WG) acc4[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
     if (threadIdx.x < 64) fb_hits[threadIdx.x] = 0;
-    if (s.fb_mask) {
-        for (uint32_t j = threadIdx.x; j < FB_CACHE; j += OWN_WG) {
-            fb_keys(fb_hits)[j] = FB_EMPTY;
-            fb_vals(fb_hits)[j] = 0ull;
-        }
-    }
     __syncthreads();
     own_dispatch<N, 0>(acc, s, recs, B, hits, dst, cdst, fb_hits, scale, cbits);
     __syncthreads();
@@ -752,17 +746,6 @@ __global__ __launch_bounds__(OWN_WG) void k_td_update_owner(float* dst, float* c
         } else {
             if (v != 0.0f) __hip_atomic_fetch_add(&dst[s.dlo + j], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (cnt != 0.0f) __hip_atomic_fetch_add(&cdst[s.dlo + j], cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-    if (s.fb_mask && fixed) {       // what the fallback cache holds: one add per slot and workgroup
-        for (uint32_t j = threadIdx.x; j < FB_CACHE; j += OWN_WG) {
-            const uint32_t dslot = fb_keys(fb_hits)[j];
-            if (dslot == FB_EMPTY) continue;
-            const unsigned long long word = fb_vals(fb_hits)[j];
-            const unsigned long long n = word & cmask;
-            const float v = (float)((double)((long long)(word - n) >> cbits) * (double)inv_scale);
-            if (v != 0.0f) __hip_atomic_fetch_add(&dst[dslot], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (n) __hip_atomic_fetch_add(&cdst[dslot], (float)n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     if (threadIdx.x == 0) wg_clock[2 * blockIdx.x + 1] = wall_clock64();
