@@ -566,8 +566,14 @@ __device__ __forceinline__ void own_run(float* acc, const Slice& s, const TdRecs
         const uint32_t first = s.xcd ? s.part / per_xcd + 8u * (s.part % per_xcd) : s.part, stride = s.xcd ? 8u * per_xcd : s.nparts;
         // (two blocks per turn: the second one's 4 loads are out before the first one's adds — owner 0.0727 -> 0.0708 ms; three: no better.
         // The loop has to stay this plain for it: a hand-out of blocks through a bit pattern cost 10 %, profiles/r03_experiments.txt item 19)
-        _Pragma("unroll 2") for (uint32_t blk = first; blk < nblk; blk += stride) {
-            const uint32_t base0 = blk * BLK;
+        // Every workgroup starts its round at a block of its own (a hash of its number) and wraps: the scanners of all chunks walk
+        // the same record blocks of their XCD, and walking them in step they all ask the same few L2 channels for the same lines at
+        // the same time.  Staggered: owner 0.062 -> 0.058 ms, step -1.3 ... -2.3 % in four A/Bs (profiles/r04_experiments.txt item 14).
+        const uint32_t nmine = first < nblk ? (nblk - first + stride - 1) / stride : 0u;
+        const uint32_t rot = nmine ? ((blockIdx.x * 2654435761u) >> 16) % nmine : 0u;
+        _Pragma("unroll 2") for (uint32_t k = 0; k < nmine; ++k) {
+            const uint32_t kk = k + rot >= nmine ? k + rot - nmine : k + rot;
+            const uint32_t base0 = (first + kk * stride) * BLK;
             uint32_t idx[U][NI];            // (V < 5: the record's index words as stored, idx[u][0 .. 1])
             float dw[U];
 #pragma unroll
@@ -807,13 +813,25 @@ __device__ __forceinline__ void mirror_stats(const StatMirror& m) {
 
 // table_i[perm_i(k)] += v for every member i of the orbit; `dacc` (may be null) mirrors the add (g2048_delta_begin)
 __device__ __forceinline__ void add_to_members(float* w, float* dacc, const OrbitInfo& oi, uint32_t k, float v) {
-    for (uint32_t m = 0; m < oi.nmem; ++m) {
+    // The members are different features: their slots are distinct, so all the loads go out before the first store (written as
+    // `w[slot] += v` in a loop the compiler has to keep in order, eight dependent round trips per thread; worth 0.5 - 0.8 us per launch).
+    uint32_t slot[MAX_MEMBERS];
+    float old[MAX_MEMBERS], dold[MAX_MEMBERS];
+#pragma unroll
+    for (uint32_t m = 0; m < MAX_MEMBERS; ++m) {
+        if (m >= oi.nmem) break;
         // (the four- and five-cell tables of n >= 4 live in table_place order, the f_6 tables in hex_place order, n = 2, 3 in index order)
-        const uint32_t slot = oi.radix != 16u ? oi.off[m] + permute_hex_placed(k, oi.perm[m])
-                                              : oi.digits >= 4u ? table_place(oi.off[m] + permute_digits(k, oi.perm[m], oi.digits, 16u))
-                                                                : oi.off[m] + permute_digits(k, oi.perm[m], oi.digits, 16u);
-        w[slot] += v;
-        if (dacc) dacc[slot] += v;
+        slot[m] = oi.radix != 16u ? oi.off[m] + permute_hex_placed(k, oi.perm[m])
+                                  : oi.digits >= 4u ? table_place(oi.off[m] + permute_digits(k, oi.perm[m], oi.digits, 16u))
+                                                    : oi.off[m] + permute_digits(k, oi.perm[m], oi.digits, 16u);
+        old[m] = w[slot[m]];
+        if (dacc) dold[m] = dacc[slot[m]];
+    }
+#pragma unroll
+    for (uint32_t m = 0; m < MAX_MEMBERS; ++m) {
+        if (m >= oi.nmem) break;
+        w[slot[m]] = old[m] + v;
+        if (dacc) dacc[slot[m]] = dold[m] + v;
     }
 }
 
