@@ -387,9 +387,8 @@ __device__ __forceinline__ long long to_fixed(float dw, double scale) {
 // One-pass mean rule (cbits > 0): the low `cbits` bits of a fixed-point slot count the adds, the rest is the sum — every
 // add is (dw * 2^S << cbits) + 1, the flush splits the word again (k_td_update_owner).  cbits = 0: sums only.
 __device__ __forceinline__ unsigned long long packed_add(float dw, double scale, uint32_t cbits) {
-    unsigned long long fixed = (unsigned long long)to_fixed(dw, scale);
-    if (cbits) fixed = (fixed << cbits) + 1ull;         // (wave-uniform: the sum rule skips the 64-bit shift and add)
-    return fixed;
+    const long long fixed = to_fixed(dw, scale);
+    return ((unsigned long long)fixed << cbits) + (cbits ? 1ull : 0ull);
 }
 
 // A fallback add — to a chunk of the orbit that no workgroup holds — goes straight to D.  (A small {D slot, packed sum} cache in
