@@ -400,7 +400,7 @@ __device__ __forceinline__ void fb_add(float* D, float* Dc, uint32_t dslot, floa
     if (Dc) __hip_atomic_fetch_add(&Dc[dslot], 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <int N, int F0, int FC, bool FB, bool FIXED, uint32_t IMAGES>
+template <int N, int F0, int FC, bool FB, bool FIXED, uint32_t IMAGES, bool QPLAIN>
 __device__ __forceinline__ void own_accum(const Packed& p, float dw, bool valid, float* acc, const Slice& sl, uint32_t& nhit, float* D,
                                           float* Dc, uint32_t* fb_hits, float scale, uint32_t cbits) {
     constexpr int F = Shape<N>::F;
@@ -415,7 +415,7 @@ __device__ __forceinline__ void own_accum(const Packed& p, float dw, bool valid,
         for (int f = F0; f < F0 + FC; ++f) {
             const bool cross = N >= 5 && f >= 17 && f < 21;                 // the cross orbit's table is in cross_order,
             const uint32_t rel16 = s[f] - sl.orb_tlo;                       // a four-cell orbit's in quad_place order (features.hpp)
-            const uint32_t orel = cross ? cross_order(rel16) : f < 17 ? (sl.quad_plain ? QUAD_HOT + rel16 : quad_place(rel16)) : rel16;
+            const uint32_t orel = cross ? cross_order(rel16) : f < 17 ? (QPLAIN ? QUAD_HOT + rel16 : quad_place(rel16)) : rel16;
             const uint32_t local = orel - (sl.tlo - sl.orb_tlo);
             const bool hit = valid && local < sl.size;
             if (hit) {
@@ -545,7 +545,7 @@ __device__ __forceinline__ void own_accum_quad(uint32_t x, uint32_t y, float dw,
 }
 
 // KIND (four-cell orbits, V < 5): 1 = chunk 0 of the hot-first order, 2 = one of the chunks behind it, 3 = plain order (QuadOrder); else 0
-template <int N, int V, bool FB, bool FIXED, int KIND>
+template <int N, int V, bool FB, bool FIXED, int KIND, bool STAG>
 __device__ __forceinline__ void own_run(float* acc, const Slice& s, const TdRecs& recs, uint32_t B, uint32_t* hits, float* D, float* Dc,
                                         uint32_t* fb_hits, float scale, uint32_t cbits) {
     constexpr int F0 = OwnVariants<N>::f0(V), FC = OwnVariants<N>::fc(V);
@@ -568,11 +568,7 @@ __device__ __forceinline__ void own_run(float* acc, const Slice& s, const TdRecs
         // Every workgroup starts its round at a block of its own (a hash of its number) and wraps: the scanners of all chunks walk
         // the same record blocks of their XCD, and walking them in step they all ask the same few L2 channels for the same lines at
         // the same time.  Staggered: owner 0.062 -> 0.058 ms, step -1.3 ... -2.3 % in four A/Bs (profiles/r04_experiments.txt item 14).
-        const uint32_t nmine = first < nblk ? (nblk - first + stride - 1) / stride : 0u;
-        const uint32_t rot = nmine ? ((blockIdx.x * 2654435761u) >> 16) % nmine : 0u;
-        _Pragma("unroll 2") for (uint32_t k = 0; k < nmine; ++k) {
-            const uint32_t kk = k + rot >= nmine ? k + rot - nmine : k + rot;
-            const uint32_t base0 = (first + kk * stride) * BLK;
+        auto block = [&](uint32_t base0) {
             uint32_t idx[U][NI];            // (V < 5: the record's index words as stored, idx[u][0 .. 1])
             float dw[U];
 #pragma unroll
@@ -608,6 +604,17 @@ __device__ __forceinline__ void own_run(float* acc, const Slice& s, const TdRecs
                     own_accum_idx<NI, FB, FIXED>(idx[u], dw[u], dw[u] != 0.0f, acc, s, lo_rel, nhit_wave, D, Dc, fb_hits, (double)scale, cbits);
                 }
             }
+        
+        };
+        if constexpr (STAG) {       // (the hot-first kernel; the plain-order kernel keeps round 3's loop — a trained agent's step gains nothing from the stagger)
+            const uint32_t nmine = first < nblk ? (nblk - first + stride - 1) / stride : 0u;
+            const uint32_t start = first + (nmine ? ((blockIdx.x * 2654435761u) >> 16) % nmine : 0u) * stride;
+            // (two loops of round 3's form, not one counted loop with a wrapping index: that one doubled the kernel's code and
+            // spilled 1 800 scalar registers into VGPR lanes)
+            _Pragma("unroll 2") for (uint32_t blk = start; blk < nblk; blk += stride) block(blk * BLK);
+            _Pragma("unroll 2") for (uint32_t blk = first; blk < start; blk += stride) block(blk * BLK);
+        } else {
+            _Pragma("unroll 2") for (uint32_t blk = first; blk < nblk; blk += stride) block(blk * BLK);
         }
     } else {   // main records: this part's share of the lanes, OWN_UNROLL records per thread in flight; the loop bounds are
         // wave-uniform
@@ -639,7 +646,7 @@ __device__ __forceinline__ void own_run(float* acc, const Slice& s, const TdRecs
             const bool ok = r < end;
             const uint32_t rr = ok ? r : end - 1;
             if constexpr (N >= 4)
-                own_accum<N, F0, FC, FB, FIXED, IMAGES>(ld_packed(recs.qstate, rr), recs.unit ? 1.0f : recs.qdw[rr], ok, acc, s, nhit, D, Dc, fb_hits, scale,
+                own_accum<N, F0, FC, FB, FIXED, IMAGES, KIND == 3>(ld_packed(recs.qstate, rr), recs.unit ? 1.0f : recs.qdw[rr], ok, acc, s, nhit, D, Dc, fb_hits, scale,
                                                         cbits);
             else
                 own_accum_small<N, V>(ld_packed(recs.qstate, rr), recs.unit ? 1.0f : recs.qdw[rr], ok, acc, nhit, scale, cbits);
@@ -652,7 +659,10 @@ __device__ __forceinline__ void own_run(float* acc, const Slice& s, const TdRecs
     if ((threadIdx.x & 63) == 0 && nhit) atomicAdd(&hits[s.chunk], nhit);
 }
 
-template <int N, int V>
+// PLAIN: the kernel instance for the four-cell orbits' plain order (QuadOrder).  The two orders are two kernels, not one with a
+// run-time switch: with every form of the record loop in one function the scalar registers no longer fit (7 500 v_readlane in the
+// code object, 575 inside the loop that carries the fallback duty — a trained agent's busiest workgroups), with two they do.
+template <int N, int V, bool PLAIN>
 __device__ __forceinline__ void own_dispatch(float* acc, const Slice& s, const TdRecs& recs, uint32_t B, uint32_t* hits, float* D, float* Dc,
                                              uint32_t* fb_hits, float scale, uint32_t cbits) {
     if constexpr (V < OwnVariants<N>::COUNT) {
@@ -663,41 +673,41 @@ __device__ __forceinline__ void own_dispatch(float* acc, const Slice& s, const T
             const bool fb = N >= 4 && s.fb_mask;
             if constexpr (N >= 4 && V < 5) {       // a four-cell orbit: chunk 0 (all cells <= 10) or one of the four behind it
                 static_assert(own_fixed(N, V) && FIXED_SLOTS == QUAD_HOT, "four-cell orbits: fixed point, chunks of QUAD_HOT slots");
-                if (s.quad_plain) {
+                if constexpr (PLAIN) {
                     if (fb)
-                        own_run<N, V, true, true, 3>(acc, s, recs, B, hits, D, Dc, fb_hits, scale, cbits);
+                        own_run<N, V, true, true, 3, !PLAIN>(acc, s, recs, B, hits, D, Dc, fb_hits, scale, cbits);
                     else
-                        own_run<N, V, false, true, 3>(acc, s, recs, B, hits, D, Dc, fb_hits, scale, cbits);
+                        own_run<N, V, false, true, 3, !PLAIN>(acc, s, recs, B, hits, D, Dc, fb_hits, scale, cbits);
                 } else if (s.tlo == s.orb_tlo) {
                     if (fb)
-                        own_run<N, V, true, true, 1>(acc, s, recs, B, hits, D, Dc, fb_hits, scale, cbits);
+                        own_run<N, V, true, true, 1, !PLAIN>(acc, s, recs, B, hits, D, Dc, fb_hits, scale, cbits);
                     else
-                        own_run<N, V, false, true, 1>(acc, s, recs, B, hits, D, Dc, fb_hits, scale, cbits);
+                        own_run<N, V, false, true, 1, !PLAIN>(acc, s, recs, B, hits, D, Dc, fb_hits, scale, cbits);
                 } else {
                     if (fb)
-                        own_run<N, V, true, true, 2>(acc, s, recs, B, hits, D, Dc, fb_hits, scale, cbits);
+                        own_run<N, V, true, true, 2, !PLAIN>(acc, s, recs, B, hits, D, Dc, fb_hits, scale, cbits);
                     else
-                        own_run<N, V, false, true, 2>(acc, s, recs, B, hits, D, Dc, fb_hits, scale, cbits);
+                        own_run<N, V, false, true, 2, !PLAIN>(acc, s, recs, B, hits, D, Dc, fb_hits, scale, cbits);
                 }
             } else if (own_fixed(N, V) || s.fixed) {
                 if (fb)
-                    own_run<N, V, true, true, 0>(acc, s, recs, B, hits, D, Dc, fb_hits, scale, cbits);
+                    own_run<N, V, true, true, 0, !PLAIN>(acc, s, recs, B, hits, D, Dc, fb_hits, scale, cbits);
                 else
-                    own_run<N, V, false, true, 0>(acc, s, recs, B, hits, D, Dc, fb_hits, scale, cbits);
+                    own_run<N, V, false, true, 0, !PLAIN>(acc, s, recs, B, hits, D, Dc, fb_hits, scale, cbits);
             } else if constexpr (!own_fixed(N, V)) {
                 if (fb)
-                    own_run<N, V, true, false, 0>(acc, s, recs, B, hits, D, Dc, fb_hits, scale, cbits);
+                    own_run<N, V, true, false, 0, !PLAIN>(acc, s, recs, B, hits, D, Dc, fb_hits, scale, cbits);
                 else
-                    own_run<N, V, false, false, 0>(acc, s, recs, B, hits, D, Dc, fb_hits, scale, cbits);
+                    own_run<N, V, false, false, 0, !PLAIN>(acc, s, recs, B, hits, D, Dc, fb_hits, scale, cbits);
             }
         } else
-            own_dispatch<N, V + 1>(acc, s, recs, B, hits, D, Dc, fb_hits, scale, cbits);
+            own_dispatch<N, V + 1, PLAIN>(acc, s, recs, B, hits, D, Dc, fb_hits, scale, cbits);
     }
 }
 
 // `dst` is the orbit table D (n >= 4) or the weight table itself (n = 2, 3).  `cdst` (null unless the per-slot mean rule runs
 // in one pass): where the add counts go — the accumulation then packs count and sum into one 64-bit LDS word.
-template <int N>
+template <int N, bool PLAIN>
 __global__ __launch_bounds__(OWN_WG) void k_td_update_owner(float* dst, float* cdst, TdRecs recs, uint32_t B, const Slice* slices, uint32_t* hits,
                                                             uint64_t* wg_clock) {
     __shared__ __attribute__((aligned(16))) float acc[OWN_SLOTS];
@@ -730,7 +740,7 @@ __global__ __launch_bounds__(OWN_WG) void k_td_update_owner(float* dst, float* c
     }
     if (threadIdx.x < 64) fb_hits[threadIdx.x] = 0;
     __syncthreads();
-    own_dispatch<N, 0>(acc, s, recs, B, hits, dst, cdst, fb_hits, scale, cbits);
+    own_dispatch<N, 0, PLAIN>(acc, s, recs, B, hits, dst, cdst, fb_hits, scale, cbits);
     __syncthreads();
     if (threadIdx.x < 64 && fb_hits[threadIdx.x]) atomicAdd(&hits[s.chunk0 + threadIdx.x], fb_hits[threadIdx.x]);
     const unsigned long long cmask = (1ull << cbits) - 1ull;
@@ -2585,12 +2595,20 @@ int launch_td_step(g2048_ctx* c, float alpha, hipEvent_t ev = nullptr, hipEvent_
             one_pass = c->knob.mean_one_pass && !c->plan.empty() && adds < (1ull << 21);
             TdRecs ones = recs;
             ones.unit = 1;
-            if (!one_pass) BY_N(c, (k_td_update_owner<N><<<c->n_slices, OWN_WG, 0, c->stream>>>(Ccur, nullptr, ones, B, c->slices, c->hits, c->wg_clock)));
+            if (!one_pass) {
+                if (c->quad_plain || c->n < 4)
+                    BY_N(c, (k_td_update_owner<N, true><<<c->n_slices, OWN_WG, 0, c->stream>>>(Ccur, nullptr, ones, B, c->slices, c->hits, c->wg_clock)))
+                else
+                    BY_N(c, (k_td_update_owner<N, false><<<c->n_slices, OWN_WG, 0, c->stream>>>(Ccur, nullptr, ones, B, c->slices, c->hits, c->wg_clock)))
+            }
             if (c->n == 6 && !hex_binned) k_td_update_tail<6><<<tail_grid, OWN_WG, 0, c->stream>>>(c->Dcnt, ones, B, c->orbits.o[6].base, c->orbits.o[7].base);
         }
         float* dst = Dcur;
         float* cdst = one_pass ? Ccur : nullptr;
-        BY_N(c, (k_td_update_owner<N><<<c->n_slices, OWN_WG, 0, c->stream>>>(dst, cdst, recs, B, c->slices, c->hits, c->wg_clock)));
+        if (c->quad_plain || c->n < 4)      // (n = 2, 3 have one form: the PLAIN instance)
+            BY_N(c, (k_td_update_owner<N, true><<<c->n_slices, OWN_WG, 0, c->stream>>>(dst, cdst, recs, B, c->slices, c->hits, c->wg_clock)))
+        else
+            BY_N(c, (k_td_update_owner<N, false><<<c->n_slices, OWN_WG, 0, c->stream>>>(dst, cdst, recs, B, c->slices, c->hits, c->wg_clock)))
         if (ev_owner) (void)hipEventRecord(ev_owner, c->stream);
         if (hex_binned) {           // the f_6 orbits: bin the (slot, dw) pairs by table chunk, then LDS owners (k_hex_*)
             const uint32_t hb = c->orbits.o[6].base;
