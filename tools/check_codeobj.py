@@ -299,6 +299,19 @@ def main():
             print(f'[codeobj] {short}: {sum(1 for _, x, _ in ins if x.startswith("s_barrier"))} s_barrier, {unguarded} with a store in front and no vmcnt(0) wait')
             if unguarded:
                 failures.append(f'{short}: a global store reaches an s_barrier without s_waitcnt vmcnt(0) (mirror_stats publishes host-visible data behind that barrier)')
+        # k_td_update_owner<N, PLAIN> (n >= 4): scalar registers spilled to VGPR lanes.  The record loops of these kernels are bound by
+        # instruction issue; round 4 once shipped a form with 7 543 v_readlane_b32 in one instance (575 inside the loop a trained
+        # agent's busiest workgroups run) and lost 5 % of that agent's step to it (profiles/r04_experiments.txt item 16).
+        for k in sorted(notes):
+            m = re.search(r'k_td_update_ownerILi([456])ELb([01])E', k)
+            if not m:
+                continue
+            ins = disassemble(where[k], k)
+            spills = sum(1 for _, x, _ in ins if x.startswith('v_readlane_b32'))
+            limit = 120 if m.group(2) == '1' else 500
+            print(f'[codeobj] k_td_update_owner<{m.group(1)}, {"plain" if m.group(2) == "1" else "hot-first"}>: {len(ins)} instructions, {spills} v_readlane_b32')
+            if spills > limit:
+                failures.append(f'k_td_update_owner<{m.group(1)}, PLAIN={m.group(2)}>: {spills} v_readlane_b32 (limit {limit}): the scalar registers no longer fit the record loops')
     if failures:
         print('\n'.join('[codeobj] FAIL: ' + f for f in failures))
         return 1
